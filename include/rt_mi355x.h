@@ -1,0 +1,171 @@
+/* rt_mi355x.h -- C ABI of the MI355X rendering back end for colobrodo/raytracer-rs.
+ *
+ * The library replaces the reference's per-pixel render loop and everything it calls
+ * (src/main.rs:153-171 -> cast main.rs:57-132 -> hit core.rs:68-92 -> Solid::hit core.rs:180-213
+ * -> ray_intersect core.rs:94-178 -> Triangle::intersect model.rs:43-74 ...).  The caller (the
+ * reference's main(), through the thin FFI crate shown in INTEGRATION.md) keeps the scene parser,
+ * OBJ loader, transforms, grid construction and BMP writer; it hands over a FLATTENED scene
+ * (plain pointers and sizes, caller-owned) and receives the f64 framebuffer `pixels`
+ * (main.rs:153, read back at main.rs:176-178).
+ *
+ * All entry points return 0 on success and a negative rtm_status on error; the message is
+ * available from rtm_last_error().  Nothing unwinds across this boundary.  Single caller
+ * thread per process (the reference renders once from main(), main.rs:158); not re-entrant.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTM_NO_ID 0xFFFFFFFFu /* miss (obj_id) / not a triangle (tri_id) */
+
+typedef enum rtm_status {
+    RTM_OK = 0,
+    RTM_ERR_INVALID = -1,   /* bad argument / inconsistent scene buffers */
+    RTM_ERR_DEVICE = -2,    /* HIP runtime error (no GPU, out of memory, launch failure) */
+    RTM_ERR_PARSE = -3,     /* front end: scene text error, carries "msg at line:col" (parser.rs:43-75) */
+    RTM_ERR_IO = -4,        /* front end: file could not be read ("Cannot load model", parser.rs:415-420) */
+    RTM_ERR_STATE = -5      /* rtm_init not called / handle already freed */
+} rtm_status;
+
+/* Camera fields of camera.rs:4-10 (private in the reference: the FFI crate adds accessors). */
+typedef struct rtm_camera {
+    double position[3];
+    double forward[3];
+    double up[3];
+    double right[3];
+    double zoom;
+} rtm_camera;
+
+/* One Solid::Model (core.rs:52) = Model (model.rs:9-14) + ModelGrid (model.rs:205-210), flattened.
+ * Triangle i, corner k, component c lives in pos[k*3+c][i]: nine SoA arrays of n_tris doubles, holding
+ * Model::get_triangle(i) (model.rs:108-122) evaluated once (a pure function of the vertex);
+ * nrm[...] likewise holds get_triangle_normals(i) (model.rs:125-139), i.e. already transformed by
+ * normal_trasform INCLUDING the /w and normalised. */
+typedef struct rtm_model {
+    double bbox_center[3];        /* Box3.center          (box3D.rs:5)  */
+    double bbox_half[3];          /* Box3.half_extension  (box3D.rs:6)  */
+    uint32_t cells_per_side;      /* ModelGrid.cells_per_side (32, core.rs:62) */
+    uint32_t n_tris;
+    const uint32_t* offsets;      /* ModelGrid.offset_array: INCLUSIVE prefix sums, cells_per_side^3 entries */
+    const uint32_t* tri_idx;      /* ModelGrid.triangle_indices */
+    uint64_t n_tri_idx;           /* == offsets[cells^3-1] */
+    const double* pos[9];         /* v0x v0y v0z v1x v1y v1z v2x v2y v2z */
+    const double* nrm[9];         /* n0x ... n2z */
+    uint32_t mat_idx;
+    uint32_t obj_idx;             /* index in Scene.objects (file order); ties go to the lower one (core.rs:79) */
+} rtm_model;
+
+typedef struct rtm_scene {
+    rtm_camera camera;
+    uint32_t n_objects;           /* Scene.objects.len() (core.rs:13) */
+    /* Solid::Sphere (core.rs:50), SoA, any order; obj idx keeps file order */
+    uint32_t n_spheres;
+    const double *sph_cx, *sph_cy, *sph_cz, *sph_r;
+    const uint32_t *sph_mat, *sph_obj;
+    /* Solid::Plane (core.rs:51); normal as written in the scene file, NOT normalised */
+    uint32_t n_planes;
+    const double *pl_nx, *pl_ny, *pl_nz, *pl_d;
+    const uint32_t *pl_mat, *pl_obj;
+    uint32_t n_models;
+    const rtm_model* models;
+    /* Light (core.rs:17-21) */
+    uint32_t n_lights;
+    const double *li_px, *li_py, *li_pz, *li_r, *li_g, *li_b, *li_radius;
+    /* Material (core.rs:30-33); type 0 = Plastic, 1 = Metal (core.rs:24-27) */
+    uint32_t n_materials;
+    const double *mat_r, *mat_g, *mat_b;
+    const uint32_t* mat_type;
+} rtm_scene;
+
+#define RTM_FLAG_ZERO_JITTER 1u /* x_offset = y_offset = 0 (known-answer tests); reference always jitters, main.rs:162-163 */
+
+typedef struct rtm_params {
+    uint32_t width, height;       /* ImageData.width/height (parser.rs:80-81) */
+    uint32_t spp;                 /* args.sample_rate (main.rs:27), >= 1 */
+    uint32_t max_bounces;         /* K in cast (main.rs:63); reference value 10; 1..64 */
+    uint64_t seed;                /* Philox key; replaces the OS-seeded thread_rng (main.rs:162) */
+    uint32_t row_begin;           /* rows y = row_begin + k*row_stride are rendered and packed densely:   */
+    uint32_t row_stride;          /*   out row k <-> image row y (static row-interleave across GPUs); >= 1 */
+    uint32_t flags;
+    uint32_t reserved;
+} rtm_params;
+
+/* Work counters, exact (not sampled).  rays_* count hit() queries (core.rs:68). */
+typedef struct rtm_stats {
+    uint64_t rays_camera, rays_bounce, rays_shadow;
+    uint64_t sphere_tests, plane_tests, bbox_tests, cells_visited, tri_tests, model_hits;
+} rtm_stats;
+
+typedef struct rtm_scene_dev rtm_scene_dev; /* opaque: a scene resident in HBM */
+
+/* Number of rows a params block renders: ceil((height-row_begin)/row_stride). */
+uint32_t rtm_local_rows(const rtm_params* p);
+
+/* Select the HIP device of this process (one process per GPU).  device < 0: use LOCAL_RANK or 0.
+ * No counterpart in the reference (it has no device). */
+int rtm_init(int device);
+int rtm_shutdown(void);
+const char* rtm_last_error(void);
+/* Library version string and the gfx target it was compiled for. */
+const char* rtm_version(void);
+
+/* Replaces main.rs:153-171 verbatim: fills out_rgb[(k*width + x)*3 + c] (f64, linear, unclamped; for
+ * row_begin=0,row_stride=1 that is pixels[x + width*y], main.rs:177).  Optional outputs (may be NULL):
+ * out_obj_id / out_tri_id = Scene.objects index and triangle index (core.rs:141,169) of the FIRST sample's
+ * camera-ray hit per pixel; out_stats = exact work counters.  Host pointers; uploads the scene, renders,
+ * copies back, frees. */
+int rtm_render(const rtm_scene* scene, const rtm_params* params, double* out_rgb, uint32_t* out_obj_id,
+               uint32_t* out_tri_id, rtm_stats* out_stats);
+
+/* Same path with the scene kept resident in HBM between frames (no reference counterpart: the reference
+ * holds its Scene in host memory for the life of main()). */
+int rtm_scene_upload(const rtm_scene* scene, rtm_scene_dev** out);
+int rtm_scene_free(rtm_scene_dev* scene);
+/* d_rgb / d_obj_id / d_tri_id are DEVICE pointers (local_rows*width*3 doubles / local_rows*width u32);
+ * stream is a hipStream_t (NULL = default stream).  Asynchronous unless out_stats != NULL. */
+int rtm_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, uint32_t* d_obj_id,
+                      uint32_t* d_tri_id, rtm_stats* out_stats, void* stream);
+/* Average device time (ms, HIP events on `stream`) of `iters` back-to-back rtm_render_device launches. */
+int rtm_time_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, int iters,
+                           void* stream, double* out_ms_avg);
+
+/* Closest-hit of caller-supplied rays (hit, core.rs:68-92), for differential tests: rays6 = origin xyz,
+ * direction xyz (host, n*6); outputs host arrays (obj n, tri n, t n, normal n*3). */
+int rtm_trace_rays(const rtm_scene_dev* scene, uint64_t n, const double* rays6, uint32_t* out_obj_id,
+                   uint32_t* out_tri_id, double* out_t, double* out_normal3);
+
+/* Framebuffer -> 8-bit RGB with the reference's rule (main.rs:33-48,176-185): optional gamma
+ * c>0 ? c^(1/2.2) : 0, then (c*255.0) saturating-truncating cast.  d_rgb, d_rgb8: device pointers. */
+int rtm_tonemap_device(const double* d_rgb, uint64_t n_pixels, int gamma, uint8_t* d_rgb8, void* stream);
+
+/* De-interleave gathered per-rank row blocks into the row-major framebuffer (multi-GPU assemble):
+ * d_blocks holds n_ranks blocks, block g = rows y = g + k*n_ranks packed densely; all device pointers. */
+int rtm_deinterleave_device(const double* d_blocks, uint32_t width, uint32_t height, uint32_t n_ranks,
+                            double* d_rgb, void* stream);
+
+/* ---- Host-side front end (C++ stand-in for the parts that stay in Rust: parser.rs, obj-rs load_obj,
+ * mat4.rs, Model::new model.rs:91-103, create_grid model.rs:147-201, Camera::look_at camera.rs:30-43).
+ * Produces the flattened rtm_scene the FFI crate would build.  Pure host code, no GPU needed. */
+typedef struct rtm_frontend rtm_frontend;
+/* scene_text != NULL: parse it; else read scene_path.  Model paths resolve against base_dir (the reference
+ * resolves against the cwd, core.rs:57).  flags bit 0: synthesise geometric normals for OBJ faces without
+ * `vn` (NOT reference behaviour; teapot.obj only). */
+int rtm_frontend_load(const char* scene_path, const char* scene_text, const char* base_dir, uint32_t flags,
+                      rtm_frontend** out);
+/* Append a Solid::Model built from raw f32 triangles (synthetic soup): pos9/nrm9 = n_tris*9 floats
+ * (corner-major xyz), transform16 row-major or NULL, grid = create_grid(32). */
+int rtm_frontend_add_triangles(rtm_frontend* fe, uint64_t n_tris, const float* pos9, const float* nrm9,
+                               const double* color3, uint32_t mat_type, const double* transform16);
+const rtm_scene* rtm_frontend_scene(const rtm_frontend* fe);
+int rtm_frontend_size(const rtm_frontend* fe, uint32_t* width, uint32_t* height);
+int rtm_frontend_free(rtm_frontend* fe);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */
