@@ -1,0 +1,473 @@
+// render.hip -- kernels and C ABI of the MI355X back end (gfx950 only).
+// Entry points are declared in include/rt_mi355x.h, which cites the reference interface each replaces.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_device.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local std::string g_last_error;
+int rtm_internal_fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                              \
+    do {                                                                                                           \
+        hipError_t e__ = (expr);                                                                                   \
+        if (e__ != hipSuccess)                                                                                     \
+            return rtm_internal_fail(RTM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+static int g_device = -1;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+using namespace rtd;
+
+struct RenderArgs {
+    uint32_t W, H, spp, max_bounces;
+    uint64_t seed;
+    uint32_t row_begin, row_stride, n_rows, flags;
+};
+
+RTM_DEV uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+        const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+// One pixel per lane; a wave owns an 8x8 pixel tile, a 256-thread workgroup a 16x16 tile, so the
+// 64 camera rays (and the shadow rays of their first hits) of a wave stay coherent.  All samples of
+// a pixel are accumulated by its lane in sample order (main.rs:159-170), which makes the result
+// independent of the launch geometry and bit-reproducible at any spp.
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_kernel(RtmDevScene S, RenderArgs A, double* __restrict__ out_rgb,
+                                                      uint32_t* __restrict__ out_obj, uint32_t* __restrict__ out_tri,
+                                                      unsigned long long* __restrict__ out_cnt) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ly = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    Counters cnt;
+    if (STATS)
+        for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
+    const bool live = x < A.W && ly < A.n_rows;
+    if (live) {
+        const uint32_t y = A.row_begin + ly * A.row_stride;
+        const uint32_t pixel = x + A.W * y;  // main.rs:160-161,177
+        V3 px = mk(0, 0, 0);
+        uint32_t obj0 = kNoId, tri0 = kNoId;
+        const double n_spp = (double)A.spp;
+        for (uint32_t s = 0; s < A.spp; ++s) {
+            double xo = 0.0, yo = 0.0;
+            if (!(A.flags & RTM_FLAG_ZERO_JITTER)) {  // main.rs:162-163
+                uint32_t r[4];
+                philox(A.seed, pixel, s, 0u, r);
+                xo = u01(r[0], r[1]) * (0.5 - -0.5) + -0.5;
+                yo = u01(r[2], r[3]) * (0.5 - -0.5) + -0.5;
+            }
+            V3 o, d;
+            camera_ray(S, x, y, A.W, A.H, xo, yo, o, d);
+            uint32_t fo, ft;
+            const V3 c = cast<STATS>(S, o, d, A.seed, pixel, s, (int)A.max_bounces, cnt, fo, ft);
+            if (s == 0) { obj0 = fo; tri0 = ft; }
+            px = px + c / n_spp;  // main.rs:169
+        }
+        const size_t li = (size_t)ly * A.W + x;
+        out_rgb[li * 3] = px.x;
+        out_rgb[li * 3 + 1] = px.y;
+        out_rgb[li * 3 + 2] = px.z;
+        if (out_obj) out_obj[li] = obj0;
+        if (out_tri) out_tri[li] = tri0;
+    }
+    if (STATS) {
+        for (int i = 0; i < 9; ++i) {
+            const uint64_t s = wave_sum_u64(cnt.v[i]);
+            if (lane == 0 && s) atomicAdd(out_cnt + i, (unsigned long long)s);
+        }
+    }
+}
+
+// hit() of caller-supplied rays (differential tests)
+__global__ __launch_bounds__(256) void trace_kernel(RtmDevScene S, uint64_t n, const double* __restrict__ rays, uint32_t* obj,
+                                                     uint32_t* tri, double* t_out, double* nrm_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = ld3(rays + i * 6), d = ld3(rays + i * 6 + 3);
+    Counters cnt;
+    Hit h;
+    const bool got = scene_hit<false>(S, o, d, h, cnt);
+    V3 nn = mk(0, 0, 0);
+    if (got) nn = hit_normal(S, h, o, d, ray_at(o, d, h.t));
+    obj[i] = got ? h.obj : kNoId;
+    tri[i] = got ? h.tri : kNoId;
+    t_out[i] = got ? h.t : __builtin_inf();
+    nrm_out[i * 3] = nn.x; nrm_out[i * 3 + 1] = nn.y; nrm_out[i * 3 + 2] = nn.z;
+}
+
+// main.rs:33-48,176-185: optional gamma, then (c*255.0) as u8 (truncating, saturating, NaN -> 0)
+__global__ void tonemap_kernel(const double* __restrict__ rgb, uint64_t n, int gamma, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = rgb[i];
+    if (gamma) v = v > 0.0 ? pow(v, 1.0 / 2.2) : 0.0;
+    v = v * 255.0;
+    out[i] = !(v > 0.0) ? 0 : (v >= 255.0 ? 255 : (uint8_t)v);
+}
+
+// block g of d_blocks = rows y = g + k*G, densely packed -> row-major image
+__global__ void deinterleave_kernel(const double* __restrict__ blocks, uint32_t W, uint32_t H, uint32_t G, double* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over H*W*3 doubles of the output
+    const uint64_t row_len = (uint64_t)W * 3;
+    if (i >= (uint64_t)H * row_len) return;
+    const uint32_t y = (uint32_t)(i / row_len);
+    const uint64_t within = i % row_len;
+    const uint32_t g = y % G, k = y / G;
+    // rows owned by ranks < g: ceil((H - r)/G) each
+    uint64_t base_rows = 0;
+    for (uint32_t r = 0; r < g; ++r) base_rows += (H - r + G - 1) / G;
+    out[i] = blocks[(base_rows + k) * row_len + within];
+}
+
+// ------------------------------------------------------------------------------------------------
+// device scene
+struct rtm_scene_dev {
+    RtmDevScene view;
+    std::vector<void*> allocs;
+    int device;
+};
+
+namespace {
+
+template <typename T>
+int upload(rtm_scene_dev* sd, const std::vector<T>& host, const T** out) {
+    void* p = nullptr;
+    const size_t bytes = (host.size() ? host.size() : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    sd->allocs.push_back(p);
+    if (!host.empty()) HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return RTM_OK;
+}
+
+int check_scene(const rtm_scene* s) {
+    if (!s) return rtm_internal_fail(RTM_ERR_INVALID, "scene is null");
+    if (s->n_spheres && !(s->sph_cx && s->sph_cy && s->sph_cz && s->sph_r && s->sph_mat && s->sph_obj))
+        return rtm_internal_fail(RTM_ERR_INVALID, "sphere arrays missing");
+    if (s->n_planes && !(s->pl_nx && s->pl_ny && s->pl_nz && s->pl_d && s->pl_mat && s->pl_obj))
+        return rtm_internal_fail(RTM_ERR_INVALID, "plane arrays missing");
+    if (s->n_lights && !(s->li_px && s->li_py && s->li_pz && s->li_r && s->li_g && s->li_b && s->li_radius))
+        return rtm_internal_fail(RTM_ERR_INVALID, "light arrays missing");
+    if (s->n_materials && !(s->mat_r && s->mat_g && s->mat_b && s->mat_type))
+        return rtm_internal_fail(RTM_ERR_INVALID, "material arrays missing");
+    if (s->n_models && !s->models) return rtm_internal_fail(RTM_ERR_INVALID, "model array missing");
+    for (uint32_t i = 0; i < s->n_spheres; ++i)
+        if (s->sph_mat[i] >= s->n_materials || s->sph_obj[i] >= s->n_objects)
+            return rtm_internal_fail(RTM_ERR_INVALID, "sphere material/object index out of range");
+    for (uint32_t i = 0; i < s->n_planes; ++i)
+        if (s->pl_mat[i] >= s->n_materials || s->pl_obj[i] >= s->n_objects)
+            return rtm_internal_fail(RTM_ERR_INVALID, "plane material/object index out of range");
+    for (uint32_t m = 0; m < s->n_models; ++m) {
+        const rtm_model& M = s->models[m];
+        if (M.cells_per_side == 0 || M.cells_per_side > 1024) return rtm_internal_fail(RTM_ERR_INVALID, "cells_per_side out of range");
+        if (!M.offsets || (M.n_tri_idx && !M.tri_idx)) return rtm_internal_fail(RTM_ERR_INVALID, "grid arrays missing");
+        if (M.mat_idx >= s->n_materials || M.obj_idx >= s->n_objects)
+            return rtm_internal_fail(RTM_ERR_INVALID, "model material/object index out of range");
+        for (int a = 0; a < 9; ++a)
+            if (M.n_tris && (!M.pos[a] || !M.nrm[a])) return rtm_internal_fail(RTM_ERR_INVALID, "triangle arrays missing");
+        const uint64_t n3 = (uint64_t)M.cells_per_side * M.cells_per_side * M.cells_per_side;
+        uint32_t prev = 0;
+        for (uint64_t c = 0; c < n3; ++c) {  // the kernels index tri_idx by these without further checks
+            if (M.offsets[c] < prev) return rtm_internal_fail(RTM_ERR_INVALID, "grid offsets are not non-decreasing");
+            prev = M.offsets[c];
+        }
+        if (prev != M.n_tri_idx) return rtm_internal_fail(RTM_ERR_INVALID, "grid offsets do not end at n_tri_idx");
+        for (uint64_t k = 0; k < M.n_tri_idx; ++k)
+            if (M.tri_idx[k] >= M.n_tris) return rtm_internal_fail(RTM_ERR_INVALID, "triangle index out of range");
+    }
+    return RTM_OK;
+}
+
+int check_params(const rtm_params* p) {
+    if (!p) return rtm_internal_fail(RTM_ERR_INVALID, "params is null");
+    if (p->width == 0 || p->height == 0 || p->width > 65536 || p->height > 65536)
+        return rtm_internal_fail(RTM_ERR_INVALID, "width/height out of range");
+    if (p->spp == 0) return rtm_internal_fail(RTM_ERR_INVALID, "spp must be >= 1");
+    if (p->max_bounces == 0 || p->max_bounces > 64) return rtm_internal_fail(RTM_ERR_INVALID, "max_bounces must be 1..64");
+    if (p->row_stride == 0 || p->row_begin >= p->height) return rtm_internal_fail(RTM_ERR_INVALID, "bad row_begin/row_stride");
+    if ((uint64_t)p->width * p->height > 0xFFFFFFFFull) return rtm_internal_fail(RTM_ERR_INVALID, "image too large");
+    return RTM_OK;
+}
+
+int need_init() {
+    if (g_device < 0) return rtm_internal_fail(RTM_ERR_STATE, "rtm_init has not been called");
+    return RTM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rtm_local_rows(const rtm_params* p) {
+    if (!p || p->row_stride == 0 || p->row_begin >= p->height) return 0;
+    return (p->height - p->row_begin + p->row_stride - 1) / p->row_stride;
+}
+
+int rtm_init(int device) {
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) return rtm_internal_fail(RTM_ERR_DEVICE, "no HIP device visible");
+    if (device < 0) {
+        const char* lr = std::getenv("LOCAL_RANK");
+        device = lr ? std::atoi(lr) % count : 0;
+    }
+    if (device >= count) return rtm_internal_fail(RTM_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    return RTM_OK;
+}
+
+int rtm_shutdown(void) {
+    g_device = -1;
+    return RTM_OK;
+}
+
+const char* rtm_last_error(void) { return g_last_error.c_str(); }
+const char* rtm_version(void) { return "raytracer-rs_amd 0.1 (gfx950, f64, contract=off)"; }
+
+int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
+    if (!out) return rtm_internal_fail(RTM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (int rc = need_init()) return rc;
+    if (int rc = check_scene(s)) return rc;
+    auto* sd = new rtm_scene_dev();
+    sd->device = g_device;
+    auto fail = [&](int rc) {
+        rtm_scene_free(sd);
+        return rc;
+    };
+    RtmDevScene& V = sd->view;
+    std::memset(&V, 0, sizeof V);
+    std::memcpy(V.cam_pos, s->camera.position, 24);
+    std::memcpy(V.cam_fwd, s->camera.forward, 24);
+    std::memcpy(V.cam_up, s->camera.up, 24);
+    std::memcpy(V.cam_right, s->camera.right, 24);
+    V.cam_zoom = s->camera.zoom;
+    V.n_objects = s->n_objects; V.n_spheres = s->n_spheres; V.n_planes = s->n_planes;
+    V.n_models = s->n_models; V.n_lights = s->n_lights; V.n_materials = s->n_materials;
+
+    std::vector<double> sph((size_t)s->n_spheres * 4), pl((size_t)s->n_planes * 4), li((size_t)s->n_lights * 8, 0.0),
+        mat((size_t)s->n_materials * 4);
+    std::vector<uint32_t> sph_ids((size_t)s->n_spheres * 2), pl_ids((size_t)s->n_planes * 2);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        sph[i * 4] = s->sph_cx[i]; sph[i * 4 + 1] = s->sph_cy[i]; sph[i * 4 + 2] = s->sph_cz[i]; sph[i * 4 + 3] = s->sph_r[i];
+        sph_ids[i * 2] = s->sph_mat[i]; sph_ids[i * 2 + 1] = s->sph_obj[i];
+    }
+    for (uint32_t i = 0; i < s->n_planes; ++i) {
+        pl[i * 4] = s->pl_nx[i]; pl[i * 4 + 1] = s->pl_ny[i]; pl[i * 4 + 2] = s->pl_nz[i]; pl[i * 4 + 3] = s->pl_d[i];
+        pl_ids[i * 2] = s->pl_mat[i]; pl_ids[i * 2 + 1] = s->pl_obj[i];
+    }
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        const double v[7] = {s->li_px[i], s->li_py[i], s->li_pz[i], s->li_r[i], s->li_g[i], s->li_b[i], s->li_radius[i]};
+        std::memcpy(&li[i * 8], v, sizeof v);
+    }
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        mat[i * 4] = s->mat_r[i]; mat[i * 4 + 1] = s->mat_g[i]; mat[i * 4 + 2] = s->mat_b[i];
+        mat[i * 4 + 3] = s->mat_type[i] ? 1.0 : 0.0;
+    }
+    int rc;
+    if ((rc = upload(sd, sph, &V.spheres)) || (rc = upload(sd, sph_ids, &V.sph_ids)) || (rc = upload(sd, pl, &V.planes)) ||
+        (rc = upload(sd, pl_ids, &V.pl_ids)) || (rc = upload(sd, li, &V.lights)) || (rc = upload(sd, mat, &V.materials)))
+        return fail(rc);
+
+    std::vector<RtmDevModel> models(s->n_models);
+    for (uint32_t m = 0; m < s->n_models; ++m) {
+        const rtm_model& M = s->models[m];
+        RtmDevModel& D = models[m];
+        std::memset(&D, 0, sizeof D);
+        const double n = (double)M.cells_per_side;
+        for (int c = 0; c < 3; ++c) {
+            // Pure functions of the Box3 the reference re-evaluates per call; x86-64 SSE2 and gfx950 f64
+            // +,-,/,* are both IEEE, so evaluating them once here yields the same bits.
+            D.bmin[c] = M.bbox_center[c] - M.bbox_half[c];
+            D.bmax[c] = M.bbox_center[c] + M.bbox_half[c];
+            D.cell[c] = (D.bmax[c] - D.bmin[c]) / n;
+            D.hc[c] = M.bbox_half[c] / n;
+            D.hc2[c] = D.hc[c] * 2.0;
+        }
+        D.n = M.cells_per_side; D.n_tris = M.n_tris; D.mat = M.mat_idx; D.obj = M.obj_idx;
+        const size_t n3 = (size_t)M.cells_per_side * M.cells_per_side * M.cells_per_side;
+        std::vector<uint32_t> start(n3 + 2, 0), occ((n3 + 31) / 32, 0);
+        for (size_t c = 0; c < n3; ++c) {
+            start[c + 1] = M.offsets[c];
+            if (start[c + 1] > start[c]) occ[c >> 5] |= 1u << (c & 31);
+        }
+        start[n3 + 1] = start[n3];
+        std::vector<uint32_t> idx(M.tri_idx, M.tri_idx + M.n_tri_idx);
+        std::vector<double> pos((size_t)M.n_tris * 9), nrm((size_t)M.n_tris * 9);
+        for (uint32_t t = 0; t < M.n_tris; ++t)
+            for (int a = 0; a < 9; ++a) { pos[(size_t)t * 9 + a] = M.pos[a][t]; nrm[(size_t)t * 9 + a] = M.nrm[a][t]; }
+        if ((rc = upload(sd, start, &D.cell_start)) || (rc = upload(sd, idx, &D.tri_idx)) || (rc = upload(sd, pos, &D.tri_pos)) ||
+            (rc = upload(sd, nrm, &D.tri_nrm)) || (rc = upload(sd, occ, &D.occupancy)))
+            return fail(rc);
+    }
+    if ((rc = upload(sd, models, &V.models))) return fail(rc);
+    *out = sd;
+    return RTM_OK;
+}
+
+int rtm_scene_free(rtm_scene_dev* sd) {
+    if (!sd) return RTM_OK;
+    for (void* p : sd->allocs) (void)hipFree(p);
+    delete sd;
+    return RTM_OK;
+}
+
+int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, uint32_t* d_obj, uint32_t* d_tri,
+                      rtm_stats* out_stats, void* stream_) {
+    if (int rc = need_init()) return rc;
+    if (!sd || !d_rgb) return rtm_internal_fail(RTM_ERR_INVALID, "scene or output is null");
+    if (int rc = check_params(p)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    RenderArgs A{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, rtm_local_rows(p), p->flags};
+    const dim3 grid((A.W + 15) / 16, (A.n_rows + 15) / 16), block(256);
+    if (out_stats) {
+        unsigned long long* d_cnt = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_cnt, 9 * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_cnt, 0, 9 * sizeof(unsigned long long), stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
+            e = hipGetLastError();
+        }
+        unsigned long long h[9] = {0};
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_cnt);
+        if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
+        out_stats->rays_camera = h[0]; out_stats->rays_bounce = h[1]; out_stats->rays_shadow = h[2];
+        out_stats->sphere_tests = h[3]; out_stats->plane_tests = h[4]; out_stats->bbox_tests = h[5];
+        out_stats->cells_visited = h[6]; out_stats->tri_tests = h[7]; out_stats->model_hits = h[8];
+        return RTM_OK;
+    }
+    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, (unsigned long long*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return RTM_OK;
+}
+
+int rtm_time_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, int iters, void* stream_, double* out_ms) {
+    if (!out_ms || iters <= 0) return rtm_internal_fail(RTM_ERR_INVALID, "bad iters/out");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = RTM_OK;
+    hipError_t e = hipEventRecord(e0, stream);
+    for (int i = 0; i < iters && rc == RTM_OK; ++i) rc = rtm_render_device(sd, p, d_rgb, nullptr, nullptr, nullptr, stream_);
+    if (e == hipSuccess) e = hipEventRecord(e1, stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != RTM_OK) return rc;
+    if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("timing: ") + hipGetErrorString(e));
+    *out_ms = (double)ms / iters;
+    return RTM_OK;
+}
+
+int rtm_render(const rtm_scene* scene, const rtm_params* p, double* out_rgb, uint32_t* out_obj, uint32_t* out_tri, rtm_stats* out_stats) {
+    if (int rc = need_init()) return rc;
+    if (!out_rgb) return rtm_internal_fail(RTM_ERR_INVALID, "out_rgb is null");
+    if (int rc = check_params(p)) return rc;
+    rtm_scene_dev* sd = nullptr;
+    if (int rc = rtm_scene_upload(scene, &sd)) return rc;
+    const size_t npx = (size_t)rtm_local_rows(p) * p->width;
+    double* d_rgb = nullptr;
+    uint32_t *d_obj = nullptr, *d_tri = nullptr;
+    int rc = RTM_OK;
+    auto dev = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == RTM_OK) rc = rtm_internal_fail(RTM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    dev(hipMalloc((void**)&d_rgb, npx * 24), "hipMalloc rgb");
+    if (rc == RTM_OK && out_obj) dev(hipMalloc((void**)&d_obj, npx * 4), "hipMalloc obj");
+    if (rc == RTM_OK && out_tri) dev(hipMalloc((void**)&d_tri, npx * 4), "hipMalloc tri");
+    if (rc == RTM_OK) rc = rtm_render_device(sd, p, d_rgb, d_obj, d_tri, out_stats, nullptr);
+    if (rc == RTM_OK) dev(hipDeviceSynchronize(), "render");
+    if (rc == RTM_OK) dev(hipMemcpy(out_rgb, d_rgb, npx * 24, hipMemcpyDeviceToHost), "copy rgb");
+    if (rc == RTM_OK && out_obj) dev(hipMemcpy(out_obj, d_obj, npx * 4, hipMemcpyDeviceToHost), "copy obj");
+    if (rc == RTM_OK && out_tri) dev(hipMemcpy(out_tri, d_tri, npx * 4, hipMemcpyDeviceToHost), "copy tri");
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_obj);
+    (void)hipFree(d_tri);
+    rtm_scene_free(sd);
+    return rc;
+}
+
+int rtm_trace_rays(const rtm_scene_dev* sd, uint64_t n, const double* rays6, uint32_t* out_obj, uint32_t* out_tri, double* out_t,
+                   double* out_nrm) {
+    if (int rc = need_init()) return rc;
+    if (!sd || !rays6 || !out_obj || !out_tri || !out_t || !out_nrm) return rtm_internal_fail(RTM_ERR_INVALID, "null argument");
+    if (n == 0) return RTM_OK;
+    if (n > (1ull << 31)) return rtm_internal_fail(RTM_ERR_INVALID, "too many rays");
+    double *d_rays = nullptr, *d_t = nullptr, *d_n = nullptr;
+    uint32_t *d_o = nullptr, *d_i = nullptr;
+    int rc = RTM_OK;
+    auto dev = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == RTM_OK) rc = rtm_internal_fail(RTM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    dev(hipMalloc((void**)&d_rays, n * 48), "hipMalloc");
+    dev(hipMalloc((void**)&d_t, n * 8), "hipMalloc");
+    dev(hipMalloc((void**)&d_n, n * 24), "hipMalloc");
+    dev(hipMalloc((void**)&d_o, n * 4), "hipMalloc");
+    dev(hipMalloc((void**)&d_i, n * 4), "hipMalloc");
+    if (rc == RTM_OK) dev(hipMemcpy(d_rays, rays6, n * 48, hipMemcpyHostToDevice), "copy rays");
+    if (rc == RTM_OK) {
+        hipLaunchKernelGGL(trace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, sd->view, n, d_rays, d_o, d_i, d_t, d_n);
+        dev(hipGetLastError(), "trace launch");
+        dev(hipDeviceSynchronize(), "trace");
+    }
+    if (rc == RTM_OK) {
+        dev(hipMemcpy(out_obj, d_o, n * 4, hipMemcpyDeviceToHost), "copy");
+        dev(hipMemcpy(out_tri, d_i, n * 4, hipMemcpyDeviceToHost), "copy");
+        dev(hipMemcpy(out_t, d_t, n * 8, hipMemcpyDeviceToHost), "copy");
+        dev(hipMemcpy(out_nrm, d_n, n * 24, hipMemcpyDeviceToHost), "copy");
+    }
+    (void)hipFree(d_rays); (void)hipFree(d_t); (void)hipFree(d_n); (void)hipFree(d_o); (void)hipFree(d_i);
+    return rc;
+}
+
+int rtm_tonemap_device(const double* d_rgb, uint64_t n_pixels, int gamma, uint8_t* d_rgb8, void* stream) {
+    if (int rc = need_init()) return rc;
+    if (!d_rgb || !d_rgb8) return rtm_internal_fail(RTM_ERR_INVALID, "null argument");
+    const uint64_t n = n_pixels * 3;
+    if (n == 0) return RTM_OK;
+    hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, n, gamma, d_rgb8);
+    HIP_TRY(hipGetLastError());
+    return RTM_OK;
+}
+
+int rtm_deinterleave_device(const double* d_blocks, uint32_t width, uint32_t height, uint32_t n_ranks, double* d_rgb, void* stream) {
+    if (int rc = need_init()) return rc;
+    if (!d_blocks || !d_rgb || n_ranks == 0 || n_ranks > 64) return rtm_internal_fail(RTM_ERR_INVALID, "bad argument");
+    const uint64_t n = (uint64_t)width * height * 3;
+    if (n == 0) return RTM_OK;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_blocks, width, height,
+                       n_ranks, d_rgb);
+    HIP_TRY(hipGetLastError());
+    return RTM_OK;
+}
+
+}  // extern "C"
