@@ -148,6 +148,12 @@ int rtm_tonemap_device(const double* d_rgb, uint64_t n_pixels, int gamma, uint8_
 int rtm_deinterleave_device(const double* d_blocks, uint32_t width, uint32_t height, uint32_t n_ranks,
                             double* d_rgb, void* stream);
 
+/* Test hook (no reference counterpart): evaluates on the GPU, per element, the f64 primitives the bit-exact
+ * path relies on -- out[0][i] = a/b, out[1][i] = sqrt(|a|), out[2][i] = fmin(a,b), out[3][i] = fmax(a,b),
+ * out[4][i] = a*b + a (must round twice: no FMA contraction), out[5][i] = (double)sat_u32 cell cast of a.
+ * a, b, out6 (6*n doubles) are HOST pointers. */
+int rtm_f64_ops_selftest(uint64_t n, const double* a, const double* b, double* out6);
+
 /* ---- Host-side front end (C++ stand-in for the parts that stay in Rust: parser.rs, obj-rs load_obj,
  * mat4.rs, Model::new model.rs:91-103, create_grid model.rs:147-201, Camera::look_at camera.rs:30-43).
  * Produces the flattened rtm_scene the FFI crate would build.  Pure host code, no GPU needed. */

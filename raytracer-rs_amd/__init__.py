@@ -98,6 +98,7 @@ _lib.rtm_time_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, C.c_int,
 _lib.rtm_trace_rays.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
 _lib.rtm_tonemap_device.argtypes = [_vp, C.c_uint64, C.c_int, _vp, _vp]
 _lib.rtm_deinterleave_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]
+_lib.rtm_f64_ops_selftest.argtypes = [C.c_uint64, _vp, _vp, _vp]
 _lib.rtm_frontend_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(_vp)]
 _lib.rtm_frontend_add_triangles.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, _vp]
 _lib.rtm_frontend_scene.restype = C.POINTER(RtmScene)
@@ -108,7 +109,7 @@ _lib.rtm_frontend_free.argtypes = [_vp]
 EXPORTED_SYMBOLS = (
     "rtm_local_rows", "rtm_init", "rtm_shutdown", "rtm_last_error", "rtm_version", "rtm_render", "rtm_scene_upload",
     "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_trace_rays", "rtm_tonemap_device",
-    "rtm_deinterleave_device", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
+    "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
     "rtm_frontend_size", "rtm_frontend_free")
 
 
@@ -287,3 +288,14 @@ def tonemap_device(d_rgb: int, n_pixels: int, gamma: bool, d_rgb8: int, stream: 
 
 def deinterleave_device(d_blocks: int, width: int, height: int, n_ranks: int, d_rgb: int, stream: int = 0):
     _check(_lib.rtm_deinterleave_device(d_blocks, width, height, n_ranks, d_rgb, stream or None))
+
+
+def f64_ops_selftest(a, b) -> np.ndarray:
+    """Device evaluation of a/b, sqrt|a|, fmin, fmax, a*b+a (unfused), cell cast -- rows of the result."""
+    if not _inited:
+        init()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros((6, a.size))
+    _check(_lib.rtm_f64_ops_selftest(a.size, _ptr(a), _ptr(b), _ptr(out)))
+    return out

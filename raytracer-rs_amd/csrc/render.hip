@@ -127,6 +127,18 @@ __global__ void tonemap_kernel(const double* __restrict__ rgb, uint64_t n, int g
     out[i] = !(v > 0.0) ? 0 : (v >= 255.0 ? 255 : (uint8_t)v);
 }
 
+__global__ void f64_ops_kernel(uint64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b[i];
+    out[i] = x / y;
+    out[n + i] = __builtin_sqrt(fabs(x));
+    out[2 * n + i] = fmin(x, y);
+    out[3 * n + i] = fmax(x, y);
+    out[4 * n + i] = x * y + x;
+    out[5 * n + i] = (double)cell_coord(x, 32);
+}
+
 // block g of d_blocks = rows y = g + k*G, densely packed -> row-major image
 __global__ void deinterleave_kernel(const double* __restrict__ blocks, uint32_t W, uint32_t H, uint32_t G, double* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over H*W*3 doubles of the output
@@ -446,6 +458,29 @@ int rtm_trace_rays(const rtm_scene_dev* sd, uint64_t n, const double* rays6, uin
         dev(hipMemcpy(out_nrm, d_n, n * 24, hipMemcpyDeviceToHost), "copy");
     }
     (void)hipFree(d_rays); (void)hipFree(d_t); (void)hipFree(d_n); (void)hipFree(d_o); (void)hipFree(d_i);
+    return rc;
+}
+
+int rtm_f64_ops_selftest(uint64_t n, const double* a, const double* b, double* out6) {
+    if (int rc = need_init()) return rc;
+    if (!a || !b || !out6 || n == 0 || n > (1ull << 28)) return rtm_internal_fail(RTM_ERR_INVALID, "bad argument");
+    double *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    int rc = RTM_OK;
+    auto dev = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == RTM_OK) rc = rtm_internal_fail(RTM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    dev(hipMalloc((void**)&d_a, n * 8), "hipMalloc");
+    dev(hipMalloc((void**)&d_b, n * 8), "hipMalloc");
+    dev(hipMalloc((void**)&d_o, n * 48), "hipMalloc");
+    if (rc == RTM_OK) dev(hipMemcpy(d_a, a, n * 8, hipMemcpyHostToDevice), "copy");
+    if (rc == RTM_OK) dev(hipMemcpy(d_b, b, n * 8, hipMemcpyHostToDevice), "copy");
+    if (rc == RTM_OK) {
+        hipLaunchKernelGGL(f64_ops_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, d_a, d_b, d_o);
+        dev(hipGetLastError(), "launch");
+        dev(hipDeviceSynchronize(), "f64 ops");
+    }
+    if (rc == RTM_OK) dev(hipMemcpy(out6, d_o, n * 48, hipMemcpyDeviceToHost), "copy");
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
     return rc;
 }
 

@@ -1,0 +1,257 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called through the C ABI, against the
+CPU oracle on the same seeded inputs and against the committed golden fixtures.
+
+Bars (BASELINE.json north_star): closest-hit primitive ids bit-exact at 1 spp; colour within 1e-4 absolute per
+channel at 1 spp; PSNR >= 45 dB at N spp.  The kernel accumulates samples in the reference's order, so these
+tests additionally require the f64 framebuffer to be BIT-IDENTICAL and say so when it is not.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, ROOT, SCENES
+
+pytestmark = pytest.mark.gpu
+COLOUR_TOL = 1e-4   # north_star: absolute, per channel, at 1 spp
+PSNR_MIN_DB = 45.0  # north_star: at N spp
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.clip(a, 0, 1) - np.clip(b, 0, 1)) ** 2))
+    return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
+
+
+def assert_frames_match(g, c, what):
+    assert np.array_equal(g["obj_id"], c["obj_id"]), f"{what}: object ids differ"
+    assert np.array_equal(g["tri_id"], c["tri_id"]), f"{what}: triangle ids differ"
+    err = float(np.abs(g["rgb"] - c["rgb"]).max())
+    assert err <= COLOUR_TOL, f"{what}: max colour error {err}"
+    nbits = int((g["rgb"].view(np.uint64) != c["rgb"].view(np.uint64)).sum())
+    assert nbits == 0, f"{what}: {nbits} f64 words differ (max abs err {err})"
+
+
+def test_f64_primitives_are_ieee(rtm_gpu):
+    """device /, sqrt, fmin, fmax, unfused a*b+a and the saturating cell cast vs the host (x86-64
+    SSE2 is IEEE-754 correctly rounded), on 10^7 random + edge inputs.  Bar: bit-exact."""
+    rng = np.random.default_rng(1)
+    n = 10_000_000
+    a = rng.standard_normal(n) * np.exp(rng.uniform(-40, 40, n))
+    b = rng.standard_normal(n) * np.exp(rng.uniform(-40, 40, n))
+    edge = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1e308, 31.0,
+                     31.999999999999996, 32.0, 1e-5, 0.001, 3.0, 1 / 3.0])
+    ea, eb = np.meshgrid(edge, edge)
+    a[: ea.size] = ea.ravel()
+    b[: eb.size] = eb.ravel()
+    out = rtm_gpu.f64_ops_selftest(a, b)
+    with np.errstate(all="ignore"):
+        exp = np.stack([a / b, np.sqrt(np.abs(a)), np.fmin(a, b), np.fmax(a, b), a * b + a,
+                        np.where(a > 0, np.minimum(np.nan_to_num(np.floor(np.where(a > 0, a, 0)), posinf=31), 31), 0)])
+    for k, name in enumerate(("div", "sqrt", "fmin", "fmax", "mul_add_unfused", "cell_cast")):
+        g, e = out[k], exp[k]
+        both_nan = np.isnan(g) & np.isnan(e)
+        same = (g.view(np.uint64) == e.view(np.uint64)) | both_nan
+        if name in ("fmin", "fmax"):  # +0/-0 choice is unspecified for min/max (Rust's f64::min too)
+            same |= (g == 0) & (e == 0)
+        assert same.all(), f"{name}: {int((~same).sum())} of {n} differ, e.g. a={a[~same][0]!r} b={b[~same][0]!r}"
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_full_size_1spp_matches_oracle(name, rtm_gpu, rtm_scene, oracle_scene):
+    """BASELINE configs 1-4 at the reference's own 1200x1200, 1 spp, same seed."""
+    g = rtm_scene(name).render(spp=1, seed=11, stats=True)
+    c = oracle_scene(name).render(spp=1, seed=11)
+    assert g["rgb"].shape == (1200, 1200, 3)
+    assert_frames_match(g, c, name)
+    assert g["counters"] == c["counters"]
+    assert g["counters"]["rays_camera"] == 1200 * 1200
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_golden_fixtures(name, rtm_gpu, rtm_scene):
+    """Committed oracle outputs (tests/golden/make_golden.py): 96x96, 1 spp ids + colour, 4 spp colour."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_96.npz"))
+    size, seed = int(z["size"]), int(z["seed"])
+    g1 = rtm_scene(name).render(spp=1, seed=seed, width=size, height=size, stats=True)
+    assert_frames_match(g1, dict(rgb=z["rgb_1spp"], obj_id=z["obj_id"], tri_id=z["tri_id"]), name + " golden")
+    assert [g1["counters"][k] for k in rtm_gpu.STAT_NAMES] == z["counters_1spp"].tolist()
+    g4 = rtm_scene(name).render(spp=4, seed=seed, width=size, height=size)
+    assert psnr(g4["rgb"], z["rgb_4spp"]) >= PSNR_MIN_DB
+    assert np.array_equal(g4["rgb"], z["rgb_4spp"])
+
+
+@pytest.mark.parametrize("name", ("bunny", "multisphere"))
+def test_n_spp_psnr(name, rtm_gpu, rtm_scene, oracle_scene):
+    """N spp: PSNR >= 45 dB vs the oracle image (north_star); in-order accumulation makes it exact."""
+    g = rtm_scene(name).render(spp=20, seed=5, width=200, height=200)
+    c = oracle_scene(name).render(spp=20, seed=5, width=200, height=200)
+    assert psnr(g["rgb"], c["rgb"]) >= PSNR_MIN_DB
+    assert_frames_match(g, c, name + " 20spp")
+
+
+def test_zero_jitter_known_answer(rtm_gpu, rtm_scene):
+    """Hand-derived KAT through the C ABI (see tests/test_oracle_kat.py): centre pixel hits the sphere, corner the plane."""
+    g = rtm_scene("simple_sphere").render(spp=1, zero_jitter=True)
+    assert g["obj_id"][600, 600] == 0 and g["obj_id"][0, 0] == 1
+    assert (g["tri_id"] == rtm_gpu.NO_ID).all()
+    t = rtm_scene("simple_sphere").trace(np.array([[0, 0, 0, 0, 0, 1.0]]))
+    assert t["t"][0] == 2.0 and t["normal"][0].tolist() == [0.0, 0.0, -1.0]
+
+
+def test_row_interleave_is_invariant(rtm_gpu, rtm_scene):
+    """Multi-GPU split: rendering rows y = g (mod G) separately gives the same bits as one frame,
+    for divisible and ragged heights; rtm_deinterleave_device reassembles them."""
+    import torch
+    s = rtm_scene("bunny")
+    for (w, h, G) in ((160, 128, 4), (100, 77, 8), (64, 30, 2)):
+        full = s.render(spp=2, seed=9, width=w, height=h)
+        blocks = [s.render(spp=2, seed=9, width=w, height=h, row_begin=g, row_stride=G) for g in range(G)]
+        for g in range(G):
+            assert blocks[g]["rgb"].shape[0] == len(range(g, h, G))
+            assert np.array_equal(blocks[g]["rgb"], full["rgb"][g::G])
+            assert np.array_equal(blocks[g]["obj_id"], full["obj_id"][g::G])
+            assert np.array_equal(blocks[g]["tri_id"], full["tri_id"][g::G])
+        packed = torch.from_numpy(np.concatenate([b["rgb"] for b in blocks], axis=0)).cuda()
+        out = torch.empty(h, w, 3, dtype=torch.float64, device="cuda")
+        rtm_gpu.deinterleave_device(packed.data_ptr(), w, h, G, out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), full["rgb"])
+
+
+def test_device_entry_points_and_tonemap(rtm_gpu, rtm_scene, orc):
+    import torch
+    s = rtm_scene("suzanne")
+    w = h = 128
+    p = rtm_gpu.make_params(w, h, spp=3, seed=2)
+    rgb = torch.empty(h, w, 3, dtype=torch.float64, device="cuda")
+    obj = torch.empty(h, w, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        st = s.render_device(p, rgb.data_ptr(), d_obj=obj.data_ptr(), stats=True, stream=stream.cuda_stream)
+    stream.synchronize()
+    host = s.render(spp=3, seed=2, width=w, height=h, stats=True)
+    assert np.array_equal(rgb.cpu().numpy(), host["rgb"]) and st == host["counters"]
+    rgb8 = torch.empty(h, w, 3, dtype=torch.uint8, device="cuda")
+    rtm_gpu.tonemap_device(rgb.data_ptr(), w * h, False, rgb8.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb8.cpu().numpy(), orc.to_rgb8(host["rgb"]))  # main.rs:35-37 exact
+    rtm_gpu.tonemap_device(rgb.data_ptr(), w * h, True, rgb8.data_ptr())
+    torch.cuda.synchronize()
+    d = np.abs(rgb8.cpu().numpy().astype(int) - orc.to_rgb8(host["rgb"], gamma=True).astype(int))
+    assert d.max() <= 1  # powf on device vs libm: not bit-pinned, at most one code value (main.rs:42-48)
+
+
+def test_edge_cases(rtm_gpu, orc):
+    """Empty scene, no lights, ragged tiles, one bounce, single pixel."""
+    for txt, kw in (("size 20 13", {}),                                        # nothing to hit: sky (main.rs:127)
+                    ("size 33 17\nsphere (0,0,3) 1 red", {}),                   # no lights, ragged 16x16 tiles
+                    ("size 1 1\nplane (0,0,1) 4 metal:white\nlight (0,0,0) white", {}),
+                    ("size 40 40\nsphere (0,0,3) 1 metal:white\nplane (0,1,0) 1 white\nlight (2,-3,0) orange",
+                     dict(max_bounces=1)),
+                    ("size 40 40\nsphere (0,0,3) 1 metal:white\nplane (0,1,0) 1 white\nlight (2,-3,0) orange",
+                     dict(max_bounces=64, spp=3))):
+        g = rtm_gpu.Scene(text=txt).render(seed=4, stats=True, **kw)
+        c = orc.OracleScene(text=txt).render(seed=4, **kw)
+        assert_frames_match(g, c, txt.splitlines()[0])
+        assert g["counters"] == c["counters"]
+    sky = rtm_gpu.Scene(text="size 20 13").render()
+    assert (sky["rgb"] == 1.0).all() and (sky["obj_id"] == rtm_gpu.NO_ID).all()
+
+
+def test_argument_errors(rtm_gpu):
+    s = rtm_gpu.Scene(text="size 8 8\nsphere (0,0,3) 1 white")
+    for kw in (dict(spp=0), dict(max_bounces=0), dict(max_bounces=65), dict(row_stride=0), dict(row_begin=8)):
+        with pytest.raises(rtm_gpu.RtmError) as e:
+            s.render(**{**dict(spp=1), **kw})
+        assert e.value.code == -1
+
+
+def _random_scene_text(rng, n_sph, n_pl):
+    lines = ["size 64 64", "camera from (0.3, -0.2, -1) to (0, 0, 5)"]
+    for _ in range(n_sph):
+        c = rng.uniform(-3, 3, 3) + np.array([0, 0, 6])
+        lines.append("sphere (%.3f, %.3f, %.3f) %.3f %s" % (*c, rng.uniform(0.2, 1.5), rng.choice(["white", "metal:red", "cyan"])))
+    for _ in range(n_pl):
+        n = rng.normal(size=3)
+        lines.append("plane (%.3f, %.3f, %.3f) %.3f %s" % (*n, rng.uniform(2, 9), rng.choice(["white", "metal:white"])))
+    for _ in range(int(rng.integers(0, 4))):
+        lines.append("light (%.2f, %.2f, %.2f) %s" % (*rng.uniform(-4, 4, 3), rng.choice(["red", "green", "blue", "white"])))
+    return "\n".join(lines)
+
+
+def _soup(rng, n, centre, spread, s):
+    c = rng.uniform(-spread, spread, (n, 1, 3)) + np.asarray(centre)
+    pos = (c + rng.uniform(-s, s, (n, 3, 3))).astype(np.float32)
+    e1, e2 = pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]
+    g = np.cross(e1, e2)
+    g /= np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
+    return pos.reshape(n, 9), np.repeat(g, 3, axis=0).reshape(n, 9).astype(np.float32)
+
+
+def test_differential_fuzz_random_scenes(rtm_gpu, orc):
+    """random rays vs random small scenes (spheres, planes, triangle soups, several models so that
+    object ties and model order matter), oracle vs kernel, ids and t and normal bit-exact; includes axis-parallel
+    rays (zero direction components: quirk Q6), origins inside the grid box (Q5) and non-unit directions (Q4)."""
+    rng = np.random.default_rng(77)
+    for trial in range(6):
+        txt = _random_scene_text(rng, int(rng.integers(0, 6)), int(rng.integers(0, 3)))
+        a, b = rtm_gpu.Scene(text=txt), orc.OracleScene(text=txt)
+        for m in range(int(rng.integers(1, 3))):
+            pos, nrm = _soup(rng, int(rng.integers(50, 3000)), (rng.uniform(-1, 1), rng.uniform(-1, 1), 5.0 + m), 1.5,
+                             rng.uniform(0.05, 0.6))
+            a.add_triangles(pos, nrm, metal=bool(m))
+            b.add_triangles(pos, nrm, metal=bool(m))
+        n = 40000
+        o = rng.uniform(-4, 4, (n, 3)) + np.array([0, 0, 3.0])
+        d = rng.normal(size=(n, 3)) * rng.uniform(0.1, 3.0, (n, 1))
+        d[: n // 10, rng.integers(0, 3)] = 0.0                    # one zero component
+        d[n // 10: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8 - n // 10)] * rng.choice([-1.0, 1.0])  # axis rays
+        o[n // 2: n // 2 + 5000] = rng.uniform(-1, 1, (5000, 3)) + np.array([0, 0, 5.0])  # inside the soup's box
+        rays = np.concatenate([o, d], axis=1)
+        g, c = a.trace(rays), b.trace(rays)
+        assert np.array_equal(g["obj_id"], c["obj_id"]), f"trial {trial}"
+        assert np.array_equal(g["tri_id"], c["tri_id"]), f"trial {trial}"
+        assert np.array_equal(g["t"].view(np.uint64), c["t"].view(np.uint64)), f"trial {trial}"
+        nn = (g["normal"].view(np.uint64) != c["normal"].view(np.uint64)) & ~(np.isnan(g["normal"]) & np.isnan(c["normal"]))
+        assert not nn.any(), f"trial {trial}: {int(nn.sum())} normal words differ"
+        assert (g["obj_id"] != rtm_gpu.NO_ID).mean() > 0.05
+        # and a full render of the same random scene
+        gr = a.render(spp=2, seed=trial, stats=True)
+        cr = b.render(spp=2, seed=trial)
+        assert_frames_match(gr, cr, f"fuzz scene {trial}")
+        assert gr["counters"] == cr["counters"]
+
+
+def test_teapot_and_soup_scene(rtm_gpu, orc):
+    """BASELINE config 5 in miniature: a seeded triangle soup plus teapot.obj (no `vn`: geometric normals are
+    synthesised on both sides -- NOT reference behaviour, the reference loader refuses this file)."""
+    txt = ('size 160 160\nplane (0, 1.0, 0) 2 metal:white\n'
+           'model "./models/teapot.obj" white > scale 0.4 > translate (0, 0.5, 6)\nlight (1, -2, 2) white\nlight (-2, -1, 3) orange')
+    a = rtm_gpu.Scene(text=txt, base_dir=ASSETS, synth_normals=True)
+    b = orc.OracleScene(text=txt, base_dir=ASSETS, allow_missing_normals=True)
+    pos, nrm = _soup(np.random.default_rng(3), 20000, (0, -1, 7), 2.0, 0.05)
+    a.add_triangles(pos, nrm)
+    b.add_triangles(pos, nrm)
+    g, c = a.render(spp=2, seed=1, stats=True), b.render(spp=2, seed=1)
+    assert_frames_match(g, c, "teapot+soup")
+    assert g["counters"] == c["counters"]
+    assert (g["obj_id"] == 1).any() and (g["obj_id"] == 2).any()
+
+
+def test_full_size_20spp_properties(rtm_gpu, rtm_scene):
+    """BASELINE's headline size (bunny 1200x1200, 20 spp) is too slow for the CPU oracle inside a test, so it is
+    checked through size-independent properties: determinism (same seed -> same bits), seed sensitivity, the
+    camera-ray count, 1-spp ids embedded in the 20-spp frame, and row-split invariance on a row subset."""
+    s = rtm_scene("bunny")
+    a = s.render(spp=20, seed=0, stats=True)
+    b = s.render(spp=20, seed=0)
+    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["tri_id"], b["tri_id"])
+    c = a["counters"]
+    assert c["rays_camera"] == 1200 * 1200 * 20
+    assert c["rays_shadow"] % 2 == 0  # two lights: every hit issues exactly two shadow queries (main.rs:78-86)
+    one = s.render(spp=1, seed=0)
+    assert np.array_equal(one["obj_id"], a["obj_id"]) and np.array_equal(one["tri_id"], a["tri_id"])
+    assert np.isfinite(a["rgb"]).all() and a["rgb"].min() >= 0.0
+    part = s.render(spp=20, seed=0, row_begin=5, row_stride=64)
+    assert np.array_equal(part["rgb"], a["rgb"][5::64])
+    assert not np.array_equal(s.render(spp=20, seed=1, row_begin=5, row_stride=64)["rgb"], part["rgb"])
