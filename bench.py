@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X back end (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bunny|suzanne|multisphere|simple_sphere|soup]
+
+A "step" is one pass of the hot path over one frame: render (one rtm_render_device launch per rank on its
+interleaved rows) and, for N > 1, the RCCL gather to rank 0 plus the de-interleave.  The scene and the
+framebuffer are resident in HBM before the timed region (the PCIe-inclusive rate is in DESIGN.md).
+At N = 1 the workload is the configuration the metric is quoted on: bunny 1200x1200 at 20 spp.
+value = hit() queries (camera + bounce + shadow; counted exactly by the library's stats instantiation, which the
+parity tests pin to the oracle's counters) x K / wall seconds of the K timed steps, max over ranks.
+One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+ASSETS = os.path.join(ROOT, "assets")
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6    # public vector FP64 figure (FMA = 2 flop); BASELINE.md section 4
+
+
+def algorithmic_bytes(c: dict, w: int, h: int) -> float:
+    """SURVEY 8(d) B_ray summed with the exact counters: 48 B ray + 40 B hit record per query, 32 B per sphere or
+    plane test, 48 B per model bbox test, 8 B per cell visited, 76 B per triangle test, 72 B of normals per model
+    hit, plus the 24 B/pixel framebuffer write."""
+    rays = c["rays_camera"] + c["rays_bounce"] + c["rays_shadow"]
+    return (88.0 * rays + 32.0 * (c["sphere_tests"] + c["plane_tests"]) + 48.0 * c["bbox_tests"] + 8.0 * c["cells_visited"] +
+            76.0 * c["tri_tests"] + 72.0 * c["model_hits"] + 24.0 * w * h)
+
+
+def algorithmic_flops(c: dict) -> float:
+    """SURVEY 8(d) hand counts (div and sqrt = 1 flop each): sphere 25 to the discriminant (+6 +normal 21 when it
+    wins: folded into 31 per test as an upper-side estimate is avoided -- only the discriminant part is charged),
+    plane 17, bbox 31, DDA set-up 54 per bbox test that enters the grid (charged per model hit or miss alike via
+    bbox tests), 9 per cell step, 52 per full triangle test (30 to the u-reject: 41 on average), 66 per model hit
+    for the barycentric normal."""
+    return (25.0 * c["sphere_tests"] + 17.0 * c["plane_tests"] + 31.0 * c["bbox_tests"] + 54.0 * c["bbox_tests"] * 0.5 +
+            9.0 * c["cells_visited"] + 41.0 * c["tri_tests"] + 66.0 * c["model_hits"])
+
+
+def soup_scene(rtm, n_tris: int, seed: int):
+    """BASELINE config 5's synthetic soup: N triangles, centres U([-2,2]^3)+(0,0,7), edge vectors U([-s,s]^3)
+    with s = 0.02, geometric normals, numpy Philox(seed); two planes and two lights as in the bunny scene."""
+    import numpy as np
+    txt = ("size 1200 1200\n\ncamera from (4.0, -8, 0) to (0, 0, 7)\n\nplane (0, 0, 1.0) 10 white\n"
+           "plane (0, 1.0, 0) 2 metal:white\nlight (1, 0, 2) green\nlight (-1, 0, 2) blue")
+    s = rtm.Scene(text=txt, base_dir=ASSETS)
+    rng = np.random.Generator(np.random.Philox(seed))
+    c = rng.uniform(-2, 2, (n_tris, 1, 3)) + np.array([0.0, 0.0, 7.0])
+    pos = (c + rng.uniform(-0.02, 0.02, (n_tris, 3, 3))).astype(np.float32)
+    g = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0])
+    g /= np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
+    s.add_triangles(pos.reshape(n_tris, 9), np.repeat(g, 3, axis=0).reshape(n_tris, 9).astype(np.float32))
+    return s
+
+
+def cpu_baseline(workload: str, width: int, height: int, target_s: float = 15.0):
+    """The oracle (kind "port": C++ restatement of the rayon path, faithful-cost mode) on this box's host cores,
+    on a bounded sample of the same workload: the full frame at a reduced spp."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # CPU baseline leg only
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = max(1, min(cores, os.cpu_count() or 1))
+    sc = oracle.OracleScene(path=os.path.join(ASSETS, "scene", workload + ".scene"), base_dir=ASSETS)
+    t0 = time.perf_counter()
+    sc.render(spp=1, seed=0, width=width, height=height, faithful=True, n_threads=cores, counters=False)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(20, target_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    sc.render(spp=spp, seed=0, width=width, height=height, faithful=True, n_threads=cores, counters=False)
+    dt = time.perf_counter() - t0
+    cnt = sc.render(spp=spp, seed=0, width=width, height=height, faithful=False, n_threads=cores)["counters"]
+    rays = cnt["rays_camera"] + cnt["rays_bounce"] + cnt["rays_shadow"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{workload} {width}x{height} at {spp} spp (of 20), all pixels, faithful-cost mode "
+                      f"(per-access Mat4::apply, model.rs:108-122), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="bunny")
+    ap.add_argument("--spp", type=int, default=20)
+    ap.add_argument("--size", type=int, default=0, help="override width=height (0 = scene file's size)")
+    ap.add_argument("--soup-tris", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rtm_loader import load_package
+    rtm = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    rtm.init(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    if args.workload == "soup":
+        scene = soup_scene(rtm, args.soup_tris, 20250725)
+    else:
+        scene = rtm.Scene(path=os.path.join(ASSETS, "scene", args.workload + ".scene"), base_dir=ASSETS)
+    W = args.size or scene.width
+    H = args.size or scene.height
+    p_local = rtm.make_params(W, H, spp=args.spp, seed=0, row_begin=rank, row_stride=world)
+    rows = rtm.local_rows(p_local)
+    stream = torch.cuda.current_stream()
+    local = torch.empty(rows, W, 3, dtype=torch.float64, device="cuda")
+    scene.device_handle()  # scene resident in HBM before the timed region
+    equal_rows = H % world == 0
+    if world > 1:
+        gathered = torch.empty(world * rows if equal_rows else H + world, W, 3, dtype=torch.float64, device="cuda") if rank == 0 else None
+        frame = torch.empty(H, W, 3, dtype=torch.float64, device="cuda") if rank == 0 else None
+        if not equal_rows:
+            sys.exit("bench.py: height must be divisible by the number of GPUs")
+
+    def step():
+        scene.render_device(p_local, local.data_ptr(), stream=stream.cuda_stream)
+        if world > 1:
+            # one gather of the compact row blocks to rank 0 over xGMI (RCCL), then de-interleave
+            dist.gather(local, list(gathered.view(world, rows, W, 3).unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                rtm.deinterleave_device(gathered.data_ptr(), W, H, world, frame.data_ptr(), stream=stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # exact ray / work counts of the whole frame (outside the timed region)
+    cnt = scene.render_device(p_local, local.data_ptr(), stats=True, stream=stream.cuda_stream)
+    if world > 1:
+        t = torch.tensor([cnt[k] for k in rtm.STAT_NAMES], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        cnt = dict(zip(rtm.STAT_NAMES, (int(v) for v in t.tolist())))
+    rays = cnt["rays_camera"] + cnt["rays_bounce"] + cnt["rays_shadow"]
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant kernel: average launch duration with HIP events on the launch stream (this rank's rows)
+    kern_ms = scene.time_render_device(p_local, local.data_ptr(), max(3, min(args.steps, 10)), stream=stream.cuda_stream)
+    local_cnt = scene.render_device(p_local, local.data_ptr(), stats=True, stream=stream.cuda_stream) if world > 1 else cnt
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = rays * args.steps / dt / 1e6
+        abytes = algorithmic_bytes(local_cnt, W, rows)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.workload}_{W}x{H}_{args.spp}spp_n{world}", {}).get("hbm_bytes_per_launch")
+        flops = algorithmic_flops(local_cnt)
+        out = {
+            "metric": "Mrays/s (primary+shadow) bunny 1200^2 20spp" if args.workload == "bunny" and W == 1200 and args.spp == 20
+            else f"Mrays/s (primary+shadow) {args.workload} {W}x{H} {args.spp}spp",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "reference scene files (assets/), counter-based RNG seed 0" if args.workload != "soup"
+            else f"synthetic {args.soup_tris}-triangle soup, numpy Philox seed 20250725",
+            "config": {"workload": f"{args.workload} {W}x{H} at {args.spp} spp, 10 bounces, grid 32^3",
+                       "rays_per_frame": rays, "rays_camera": cnt["rays_camera"], "rays_bounce": cnt["rays_bounce"],
+                       "rays_shadow": cnt["rays_shadow"], "samples_per_s": W * H * args.spp * args.steps / dt,
+                       "parallelism": f"row-interleave x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "render_kernel<false>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "note": "scene <= 1.8 MB is L2-resident: the binding limit is FP64 VALU issue + divergence, see valu"},
+            "valu": {"achieved_tflops": flops / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
+                     "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "algorithmic_flops_per_launch": flops},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload != "soup":
+            out["cpu_baseline"] = cpu_baseline(args.workload, W, H)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
