@@ -84,6 +84,8 @@ typedef struct rtm_scene {
 
 #define RTM_FLAG_ZERO_JITTER 1u /* x_offset = y_offset = 0 (known-answer tests); reference always jitters, main.rs:162-163 */
 
+#define RTM_FLAG_KERNEL_V1 2u   /* use the straight per-lane kernel (rt_device.h) instead of the wave-scheduled one; same results */
+
 typedef struct rtm_params {
     uint32_t width, height;       /* ImageData.width/height (parser.rs:80-81) */
     uint32_t spp;                 /* args.sample_rate (main.rs:27), >= 1 */

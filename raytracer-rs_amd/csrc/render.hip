@@ -2,6 +2,7 @@
 // Entry points are declared in include/rt_mi355x.h, which cites the reference interface each replaces.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,6 +11,7 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_device.h"
+#include "rt_wave.h"
 
 #pragma clang fp contract(off)
 
@@ -28,6 +30,7 @@ int rtm_internal_fail(int code, const std::string& msg) {
     } while (0)
 
 static int g_device = -1;
+static uint32_t g_s_threshold = 32, g_t_min_lanes = 16;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -248,6 +251,8 @@ int rtm_init(int device) {
     if (device >= count) return rtm_internal_fail(RTM_ERR_INVALID, "device index out of range");
     HIP_TRY(hipSetDevice(device));
     g_device = device;
+    if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     return RTM_OK;
 }
 
@@ -353,16 +358,27 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     if (!sd || !d_rgb) return rtm_internal_fail(RTM_ERR_INVALID, "scene or output is null");
     if (int rc = check_params(p)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    RenderArgs A{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, rtm_local_rows(p), p->flags};
-    const dim3 grid((A.W + 15) / 16, (A.n_rows + 15) / 16), block(256);
+    const uint32_t n_rows = rtm_local_rows(p);
+    const dim3 grid((p->width + 15) / 16, (n_rows + 15) / 16), block(256);
+    const bool v1 = (p->flags & RTM_FLAG_KERNEL_V1) != 0;
+    RenderArgs A{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags};
+    rtw::RenderArgsW AW{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags,
+                        g_s_threshold, g_t_min_lanes};
+    auto launch = [&](bool stats, unsigned long long* d_cnt) {
+        if (v1) {
+            if (stats) hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
+            else hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
+        } else {
+            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, grid, block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, grid, block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+        }
+        return hipGetLastError();
+    };
     if (out_stats) {
         unsigned long long* d_cnt = nullptr;
         HIP_TRY(hipMalloc((void**)&d_cnt, 9 * sizeof(unsigned long long)));
         hipError_t e = hipMemsetAsync(d_cnt, 0, 9 * sizeof(unsigned long long), stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
-            e = hipGetLastError();
-        }
+        if (e == hipSuccess) e = launch(true, d_cnt);
         unsigned long long h[9] = {0};
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -373,8 +389,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         out_stats->cells_visited = h[6]; out_stats->tri_tests = h[7]; out_stats->model_hits = h[8];
         return RTM_OK;
     }
-    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, (unsigned long long*)nullptr);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch(false, nullptr));
     return RTM_OK;
 }
 

@@ -1,0 +1,382 @@
+// rt_wave.h -- the production render kernel: a wave-scheduled path-state machine for gfx950.
+//
+// Why this shape (DESIGN.md "Kernel"): the per-ray arithmetic is fixed by bit parity with the reference, so
+// throughput is decided by how many of a wavefront's 64 lanes do useful work per issued f64 instruction.
+// A straight transliteration of cast()/hit() (rt_device.h, kept as the `v1` kernel) runs at ~10 % lane
+// utilisation on the bunny scene: shadow rays, bounce rays and the 3D-DDA sit at different code addresses
+// and every DDA loop runs for the slowest lane.  Here every lane owns one pixel and walks the reference's
+// sequence   camera ray -> hit -> [shadow ray per light] -> bounce -> ...   (main.rs:57-132,159-170) as a
+// state machine with exactly ONE copy of each expensive block, and the wave alternates between
+//   S  "shade/set-up": consume the finished query, produce the next ray, analytic primitives, slab test,
+//                      DDA initialisation (core.rs:68-125, main.rs:65-125), run for all waiting lanes at once;
+//   T  "traverse"    : one triangle test per traversing lane per step, cell advance folded in
+//                      (core.rs:129-167, model.rs:43-74),
+// chosen per iteration from wave ballots (popcount thresholds), so lanes finishing a short DDA wait only
+// until enough lanes are ready for the next S round.  Empty cells are skipped through a cell-occupancy
+// bitmap staged in LDS (one bit per cell, derived from the offset array at upload time).
+// The arithmetic of every block is the same op sequence as rt_device.h / the reference: results are
+// bit-identical, which tests/test_parity_gpu.py checks for both kernels.
+#pragma once
+#include "rt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace rtw {
+using namespace rtd;
+
+constexpr int kOccLdsWords = 8192;  // 32 KiB of LDS for occupancy bitmaps (8 models of 32^3 cells)
+
+enum : uint32_t { ST_CONSUME = 0, ST_ENTER = 1, ST_TRAV = 2, ST_DEAD = 3 };
+enum : uint32_t { PH_START = 0, PH_PATH = 1, PH_SHADOW = 2 };
+
+struct RenderArgsW {
+    uint32_t W, H, spp, max_bounces;
+    uint64_t seed;
+    uint32_t row_begin, row_stride, n_rows, flags;
+    uint32_t s_threshold;  // run an S round when at least this many lanes wait (or nobody traverses)
+    uint32_t t_min_lanes;  // leave the T loop when fewer lanes than this still traverse and some lane waits
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderArgsW A, double* __restrict__ out_rgb,
+                                                           uint32_t* __restrict__ out_obj, uint32_t* __restrict__ out_tri,
+                                                           unsigned long long* __restrict__ out_cnt) {
+    __shared__ uint32_t occ_lds[kOccLdsWords];
+    // ---- stage the occupancy bitmaps (models are laid out back to back; those that do not fit stay in HBM)
+    {
+        uint32_t base = 0;
+        for (uint32_t m = 0; m < S.n_models; ++m) {
+            const uint32_t n = S.models[m].n;
+            const uint32_t words = (n * n * n + 31u) >> 5;
+            if (base + words > (uint32_t)kOccLdsWords) break;
+            const uint32_t* src = S.models[m].occupancy;
+            for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) occ_lds[base + i] = src[i];
+            base += words;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ly = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    Counters cnt;
+    if (STATS)
+        for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
+
+    const bool live = x < A.W && ly < A.n_rows;
+    const uint32_t y = A.row_begin + ly * A.row_stride;
+    const uint32_t pixel = x + A.W * y;  // main.rs:160-161,177
+    const double n_spp = (double)A.spp;
+    const int K = (int)A.max_bounces;
+
+    // ---- lane state ------------------------------------------------------------------------------
+    uint32_t st = live ? ST_CONSUME : ST_DEAD;
+    uint32_t phase = PH_START, s = 0, li = 0, mat = 0, model_i = 0;
+    int bounce = 0;
+    V3 px = mk(0, 0, 0), color = mk(0, 0, 0);
+    double att = 1.0;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);        // current query ray
+    V3 P = mk(0, 0, 0), nrm = mk(0, 0, 0), bd = mk(0, 0, 0), diffuse = mk(0, 0, 0);
+    double dl2 = 0.0;
+    uint32_t obj0 = kNoId, tri0 = kNoId;
+    // query result so far (core.rs:69-85)
+    double best = 0.0;
+    bool found = false;
+    uint32_t h_obj = kNoId, h_tri = kNoId, h_mat = 0, h_kind = 0, h_prim = 0;
+    // traversal state (core.rs:99-128)
+    int ix = 0, iy = 0, iz = 0, sx = 1, sy = 1, sz = 1;
+    double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
+    uint32_t k = 0, k_end = 0, m_tri = 0;
+    double m_t = 0.0;
+    bool have = false, fresh = false;
+
+    auto consider = [&](double t, uint32_t obj, uint32_t mt, uint32_t kind, uint32_t prim, uint32_t tri) {
+        if (t <= kEps) return;  // core.rs:75-77
+        if (t < best || (found && t == best && obj < h_obj)) {  // core.rs:79, ties to the earlier object
+            best = t; found = true;
+            h_obj = obj; h_mat = mt; h_kind = kind; h_prim = prim; h_tri = tri;
+        }
+    };
+
+    for (;;) {
+        const unsigned long long waiting = __ballot(st == ST_CONSUME || st == ST_ENTER);
+        const unsigned long long traversing = __ballot(st == ST_TRAV);
+        if (!waiting && !traversing) break;
+        if (!traversing || (uint32_t)__popcll(waiting) >= A.s_threshold) {
+            // =========================== S round ===========================
+            if (st == ST_CONSUME) {
+                bool gen = false, finish = false, end_sample = false;
+                if (phase == PH_PATH) {
+                    if (bounce == 0 && s == 0) { obj0 = found ? h_obj : kNoId; tri0 = found ? h_tri : kNoId; }
+                    if (!found) {
+                        color = color + mk(1, 1, 1) * att;  // main.rs:127
+                        end_sample = true;
+                    } else {
+                        P = ray_at(o, d, best);  // core.rs:89
+                        V3 nn;
+                        if (h_kind == 0u) nn = normalize(ray_at(o, d, best) - ld3(S.spheres + (size_t)h_prim * 4));  // core.rs:195
+                        else if (h_kind == 1u) nn = ld3(S.planes + (size_t)h_prim * 4);                              // core.rs:209
+                        else nn = model_normal(S.models[h_prim], h_tri, P);                                          // core.rs:169-177
+                        if (dot(d, nn) > 0.001) nn = nn * -1.0;  // main.rs:68-73
+                        nrm = nn;
+                        mat = h_mat;
+                        const bool metal = S.materials[(size_t)mat * 4 + 3] != 0.0;
+                        if (metal) {
+                            bd = d - nn * 2.0 * dot(d, nn);  // vec3.rs:172-175
+                        } else {
+                            uint32_t ra[4], rb[4];
+                            philox(A.seed, pixel, s, 1u + 2u * (uint32_t)bounce, ra);
+                            philox(A.seed, pixel, s, 2u + 2u * (uint32_t)bounce, rb);
+                            const V3 rnd = mk(u01(ra[0], ra[1]) * (1.0 - 0.0) + 0.0, u01(ra[2], ra[3]) * (1.0 - 0.0) + 0.0,
+                                              u01(rb[0], rb[1]) * (1.0 - 0.0) + 0.0);
+                            bd = normalize(nn + rnd);  // main.rs:53
+                        }
+                        diffuse = mk(0, 0, 0);
+                        li = 0;
+                        if (S.n_lights == 0u) finish = true;
+                    }
+                } else if (phase == PH_SHADOW) {  // main.rs:86-104 for light li
+                    const double* L = S.lights + (size_t)li * 8;
+                    bool occluded = false;
+                    if (found) occluded = sqdist(ray_at(o, d, best), P) <= dl2;
+                    if (!occluded) {
+                        const double eff = dot(d, nrm);
+                        if (eff > 0.001) {
+                            const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
+                            const double decay = 1.0 / dd;
+                            diffuse = diffuse + ld3(L + 3) * decay * eff;
+                        }
+                    }
+                    ++li;
+                    if (li >= S.n_lights) finish = true;
+                } else {
+                    gen = true;
+                }
+                if (finish) {  // main.rs:107-125
+                    const double* mp = S.materials + (size_t)mat * 4;
+                    const bool metal = mp[3] != 0.0;
+                    color = color + ld3(mp) * att * (diffuse * (metal ? 0.2 : 0.9));
+                    o = P;
+                    d = bd;
+                    att *= metal ? 0.8 : 0.1;
+                    ++bounce;
+                    phase = PH_PATH;
+                    if (bounce >= K) end_sample = true;
+                } else if (phase != PH_START && !end_sample) {  // next shadow query (main.rs:80-85)
+                    const double* L = S.lights + (size_t)li * 8;
+                    const V3 lp = ld3(L);
+                    o = P;
+                    d = normalize(lp - P);
+                    dl2 = sqdist(P, lp);
+                    phase = PH_SHADOW;
+                    if (STATS) cnt.v[C_SHADOW]++;
+                }
+                if (end_sample) {
+                    px = px + color / n_spp;  // main.rs:169
+                    ++s;
+                    if (s >= A.spp) {
+                        const size_t oi = (size_t)ly * A.W + x;
+                        out_rgb[oi * 3] = px.x;
+                        out_rgb[oi * 3 + 1] = px.y;
+                        out_rgb[oi * 3 + 2] = px.z;
+                        if (out_obj) out_obj[oi] = obj0;
+                        if (out_tri) out_tri[oi] = tri0;
+                        st = ST_DEAD;
+                    } else {
+                        gen = true;
+                    }
+                }
+                if (gen) {  // main.rs:160-168
+                    double xo = 0.0, yo = 0.0;
+                    if (!(A.flags & RTM_FLAG_ZERO_JITTER)) {
+                        uint32_t r[4];
+                        philox(A.seed, pixel, s, 0u, r);
+                        xo = u01(r[0], r[1]) * (0.5 - -0.5) + -0.5;
+                        yo = u01(r[2], r[3]) * (0.5 - -0.5) + -0.5;
+                    }
+                    camera_ray(S, x, y, A.W, A.H, xo, yo, o, d);
+                    color = mk(0, 0, 0);
+                    att = 1.0;
+                    bounce = 0;
+                    phase = PH_PATH;
+                }
+                if (st != ST_DEAD) {
+                    // ---- new query: analytic primitives (core.rs:183-210)
+                    if (STATS && phase == PH_PATH) cnt.v[bounce == 0 ? C_CAM : C_BOUNCE]++;
+                    best = __builtin_inf();
+                    found = false;
+                    h_obj = kNoId; h_tri = kNoId; h_mat = 0; h_kind = 0; h_prim = 0;
+                    const double a = dot(d, d);
+                    for (uint32_t i = 0; i < S.n_spheres; ++i) {
+                        if (STATS) cnt.v[C_SPHERE]++;
+                        const double* sp = S.spheres + (size_t)i * 4;
+                        const V3 oc = o - ld3(sp);
+                        const double b = 2.0 * dot(d, oc);
+                        const double c = dot(oc, oc) - sp[3] * sp[3];
+                        const double disc = b * b - 4.0 * a * c;
+                        if (disc < 0.0) continue;
+                        const double t = (-b - __builtin_sqrt(disc)) / (2.0 * a);
+                        consider(t, S.sph_ids[i * 2 + 1], S.sph_ids[i * 2], 0u, i, kNoId);
+                    }
+                    for (uint32_t i = 0; i < S.n_planes; ++i) {
+                        if (STATS) cnt.v[C_PLANE]++;
+                        const double* pp = S.planes + (size_t)i * 4;
+                        const V3 pn = ld3(pp);
+                        const double dv = dot(pn, d);
+                        if (fabs(dv) < kEps) continue;
+                        const V3 center = pn * pp[3];
+                        const double t = dot(center - o, pn) / dv;
+                        if (t < kEps) continue;
+                        consider(t, S.pl_ids[i * 2 + 1], S.pl_ids[i * 2], 1u, i, kNoId);
+                    }
+                    model_i = 0;
+                    st = ST_ENTER;
+                }
+            }
+            // ---- enter the next model whose box the ray meets (box3D.rs:64-93, core.rs:95-125); m is wave-uniform
+            {
+                for (uint32_t m = 0; m < S.n_models; ++m) {
+                    const RtmDevModel& M = S.models[m];
+                    if (st == ST_ENTER && model_i == m) {
+                        if (STATS) cnt.v[C_BBOX]++;
+                        const double fx = 1.0 / d.x, fy = 1.0 / d.y, fz = 1.0 / d.z;
+                        const double t1 = (M.bmin[0] - o.x) * fx, t2 = (M.bmax[0] - o.x) * fx;
+                        const double t3 = (M.bmin[1] - o.y) * fy, t4 = (M.bmax[1] - o.y) * fy;
+                        const double t5 = (M.bmin[2] - o.z) * fz, t6 = (M.bmax[2] - o.z) * fz;
+                        const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
+                        const double tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
+                        if (tmax < 0.0 || tmin > tmax) {
+                            model_i = m + 1;
+                        } else {
+                            const V3 P0 = ray_at(o, d, tmin);
+                            const int n = (int)M.n;
+                            ix = cell_coord((P0.x - M.bmin[0]) / M.cell[0], n);
+                            iy = cell_coord((P0.y - M.bmin[1]) / M.cell[1], n);
+                            iz = cell_coord((P0.z - M.bmin[2]) / M.cell[2], n);
+                            sx = d.x > 0.0 ? 1 : -1; sy = d.y > 0.0 ? 1 : -1; sz = d.z > 0.0 ? 1 : -1;
+                            const double nbx = (M.bmin[0] + M.hc2[0] * ((double)(ix + (sx > 0 ? 1 : 0)) + 0.5)) - M.hc[0];
+                            const double nby = (M.bmin[1] + M.hc2[1] * ((double)(iy + (sy > 0 ? 1 : 0)) + 0.5)) - M.hc[1];
+                            const double nbz = (M.bmin[2] + M.hc2[2] * ((double)(iz + (sz > 0 ? 1 : 0)) + 0.5)) - M.hc[2];
+                            tmx = (nbx - P0.x) / d.x; tmy = (nby - P0.y) / d.y; tmz = (nbz - P0.z) / d.z;
+                            tdx = ((double)sx * M.cell[0]) / d.x;
+                            tdy = ((double)sy * M.cell[1]) / d.y;
+                            tdz = ((double)sz * M.cell[2]) / d.z;
+                            have = false; fresh = true; k = 0; k_end = 0;
+                            st = ST_TRAV;
+                        }
+                    }
+                }
+                if (st == ST_ENTER) st = ST_CONSUME;  // no model left: the query is complete
+            }
+        } else {
+            // =========================== T loop ===========================
+            // all lanes traversing the same model as the first traversing lane step together (m is wave-uniform)
+            const unsigned long long trav_now = __ballot(st == ST_TRAV);
+            const int first = __ffsll((long long)trav_now) - 1;
+            const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)model_i, first);
+            uint32_t occ_base = 0;  // LDS word offset of this model's bitmap, or 0xFFFFFFFF when it stayed in HBM
+            for (uint32_t j = 0; j <= mm; ++j) {
+                const uint32_t nj = S.models[j].n;
+                const uint32_t words = (nj * nj * nj + 31u) >> 5;
+                if (occ_base + words > (uint32_t)kOccLdsWords) { occ_base = 0xFFFFFFFFu; break; }
+                if (j < mm) occ_base += words;
+            }
+            const RtmDevModel& M = S.models[mm];
+            const uint32_t n = M.n;
+            const uint32_t* __restrict__ cell_start = M.cell_start;
+            const uint32_t* __restrict__ tri_idx = M.tri_idx;
+            const double* __restrict__ tri_pos = M.tri_pos;
+            const uint32_t* __restrict__ occ_glb = M.occupancy;
+            for (;;) {
+                const bool mine = st == ST_TRAV && model_i == mm;
+                if (mine) {
+                    if (k >= k_end) {  // current cell exhausted (or first cell)
+                        if (have) {    // core.rs:147-149: first cell with any accepted hit ends the walk
+                            if (STATS) cnt.v[C_MHIT]++;
+                            consider(m_t, M.obj, M.mat, 2u, mm, m_tri);
+                            model_i = mm + 1;
+                            st = ST_ENTER;
+                        } else {
+                            bool inside = true;
+                            if (!fresh) {  // core.rs:151-167
+                                if (tmx < tmy) {
+                                    if (tmx < tmz) { ix += sx; tmx += tdx; } else { iz += sz; tmz += tdz; }
+                                } else {
+                                    if (tmy < tmz) { iy += sy; tmy += tdy; } else { iz += sz; tmz += tdz; }
+                                }
+                            }
+                            fresh = false;
+                            // skip empty cells through the occupancy bitmap: the same DDA walk, no list to scan
+                            for (;;) {
+                                inside = (unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n;  // core.rs:129-134
+                                if (!inside) break;
+                                if (STATS) cnt.v[C_CELLS]++;
+                                const uint32_t cell = ((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix;
+                                const uint32_t word = occ_base != 0xFFFFFFFFu ? occ_lds[occ_base + (cell >> 5)] : occ_glb[cell >> 5];
+                                if ((word >> (cell & 31u)) & 1u) {
+                                    k = cell_start[cell];
+                                    k_end = cell_start[cell + 1];
+                                    break;
+                                }
+                                if (tmx < tmy) {
+                                    if (tmx < tmz) { ix += sx; tmx += tdx; } else { iz += sz; tmz += tdz; }
+                                } else {
+                                    if (tmy < tmz) { iy += sy; tmy += tdy; } else { iz += sz; tmz += tdz; }
+                                }
+                            }
+                            if (!inside) {  // left the grid without a hit
+                                model_i = mm + 1;
+                                st = ST_ENTER;
+                            }
+                        }
+                    }
+                    if (st == ST_TRAV && k < k_end) {  // one triangle test (model.rs:45-72)
+                        const uint32_t ti = tri_idx[k];
+                        ++k;
+                        if (STATS) cnt.v[C_TRI]++;
+                        const double* tp = tri_pos + (size_t)ti * 9;
+                        const V3 v0 = ld3(tp), v1 = ld3(tp + 3), v2 = ld3(tp + 6);
+                        const V3 e1 = v1 - v0, e2 = v2 - v0;
+                        const V3 p = cross(d, e2);
+                        const double det = dot(e1, p);
+                        if (!(fabs(det) < kF64Eps)) {
+                            const double inv = 1.0 / det;
+                            const V3 tv = o - v0;
+                            const double u = dot(tv, p) * inv;
+                            if (!(u < 0.0 || u > 1.0)) {
+                                const V3 q = cross(tv, e1);
+                                const double v = dot(d, q) * inv;
+                                if (!(v < 0.0 || u + v > 1.0)) {
+                                    const double t = dot(e2, q) * inv;
+                                    if (!(t < 0.0) && (!have || t < m_t)) {  // core.rs:140-142
+                                        have = true;
+                                        m_t = t;
+                                        m_tri = ti;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                const unsigned long long still = __ballot(st == ST_TRAV && model_i == mm);
+                if (!still) break;
+                const unsigned long long w2 = __ballot(st == ST_CONSUME || st == ST_ENTER);
+                if ((uint32_t)__popcll(still) < A.t_min_lanes && (uint32_t)__popcll(w2) >= A.s_threshold) break;
+            }
+        }
+    }
+    if (STATS) {
+        for (int i = 0; i < 9; ++i) {
+            uint64_t v = cnt.v[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+                const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+                v += ((uint64_t)hi << 32) | lo;
+            }
+            if (lane == 0 && v) atomicAdd(out_cnt + i, (unsigned long long)v);
+        }
+    }
+}
+
+}  // namespace rtw

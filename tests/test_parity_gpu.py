@@ -56,10 +56,12 @@ def test_f64_primitives_are_ieee(rtm_gpu):
         assert same.all(), f"{name}: {int((~same).sum())} of {n} differ, e.g. a={a[~same][0]!r} b={b[~same][0]!r}"
 
 
+@pytest.mark.parametrize("kernel_v1", (False, True), ids=("wave", "v1"))
 @pytest.mark.parametrize("name", SCENES)
-def test_full_size_1spp_matches_oracle(name, rtm_gpu, rtm_scene, oracle_scene):
-    """BASELINE configs 1-4 at the reference's own 1200x1200, 1 spp, same seed."""
-    g = rtm_scene(name).render(spp=1, seed=11, stats=True)
+def test_full_size_1spp_matches_oracle(name, kernel_v1, rtm_gpu, rtm_scene, oracle_scene):
+    """BASELINE configs 1-4 at the reference's own 1200x1200, 1 spp, same seed; both kernels (the wave-scheduled
+    production kernel and the straight per-lane one) must give the oracle's bits."""
+    g = rtm_scene(name).render(spp=1, seed=11, stats=True, kernel_v1=kernel_v1)
     c = oracle_scene(name).render(spp=1, seed=11)
     assert g["rgb"].shape == (1200, 1200, 3)
     assert_frames_match(g, c, name)

@@ -19,10 +19,10 @@ for name in ['simple_sphere', 'multisphere', 'suzanne', 'bunny']:
     print(name, 'obj', eq_obj, 'tri', eq_tri, 'maxerr', err, 'differing f64 words', bits, 'stats eq', g['counters'] == c['counters'], flush=True)
     if g['counters'] != c['counters']:
         print('  gpu', g['counters']); print('  cpu', c['counters'])
-    for spp in (1, 20):
-        p = R.make_params(s.width, s.height, spp=spp, seed=0)
+    for spp, v1 in ((20, True), (1, False), (20, False)):
+        p = R.make_params(s.width, s.height, spp=spp, seed=0, kernel_v1=v1)
         buf = torch.empty(s.height * s.width * 3, dtype=torch.float64, device='cuda')
         s.time_render_device(p, buf.data_ptr(), 1)
         ms = s.time_render_device(p, buf.data_ptr(), 3)
         rays = sum(g['counters'][k] for k in ('rays_camera', 'rays_bounce', 'rays_shadow')) * spp
-        print(f'  spp={spp}: {ms:.2f} ms/frame  ~{rays/ms/1e3:.1f} Mrays/s (ray count scaled from 1spp)', flush=True)
+        print(f'  spp={spp} v1={v1}: {ms:.2f} ms/frame  ~{rays/ms/1e3:.1f} Mrays/s (ray count scaled from 1spp)', flush=True)
