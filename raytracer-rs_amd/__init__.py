@@ -23,7 +23,7 @@ except ImportError:  # torch is plumbing (device buffers, torch.distributed), no
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libraytracer_rs_amd.so")
+LIB_PATH = os.environ.get("RTM_LIB_PATH") or os.path.join(_HERE, "lib", "libraytracer_rs_amd.so")  # override: A/B builds
 INCLUDE_PATH = os.path.join(os.path.dirname(_HERE), "include", "rt_mi355x.h")
 NO_ID = 0xFFFFFFFF
 FLAG_ZERO_JITTER = 1

@@ -30,6 +30,8 @@ int rtm_internal_fail(int code, const std::string& msg) {
     } while (0)
 
 static int g_device = -1;
+static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
+static int g_num_cus = 256;
 static uint32_t g_s_threshold = 32, g_t_min_lanes = 16;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------
@@ -251,12 +253,20 @@ int rtm_init(int device) {
     if (device >= count) return rtm_internal_fail(RTM_ERR_INVALID, "device index out of range");
     HIP_TRY(hipSetDevice(device));
     g_device = device;
+    if (!g_work_counter) HIP_TRY(hipMalloc((void**)&g_work_counter, 256));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     return RTM_OK;
 }
 
 int rtm_shutdown(void) {
+    if (g_work_counter) (void)hipFree(g_work_counter);
+    g_work_counter = nullptr;
     g_device = -1;
     return RTM_OK;
 }
@@ -363,27 +373,35 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     const bool v1 = (p->flags & RTM_FLAG_KERNEL_V1) != 0;
     RenderArgs A{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags};
     rtw::RenderArgsW AW{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags,
-                        g_s_threshold, g_t_min_lanes};
+                        g_s_threshold, g_t_min_lanes, (p->width + 7) / 8, ((p->width + 7) / 8) * ((n_rows + 7) / 8), g_work_counter};
+    // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; each wave claims 8x8 tiles
+    static const uint32_t wgs_per_cu = std::getenv("RTM_WGS_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("RTM_WGS_PER_CU"))) : 4u;
+    const uint32_t wave_wgs = std::min<uint32_t>((AW.n_tiles + 3) / 4, (uint32_t)g_num_cus * wgs_per_cu);
     auto launch = [&](bool stats, unsigned long long* d_cnt) {
         if (v1) {
             if (stats) hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
             else hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
         } else {
-            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, grid, block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, grid, block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            hipError_t me = hipMemsetAsync(g_work_counter, 0, 256, stream);  // claimed tiles start at 0 every frame
+            if (me != hipSuccess) return me;
+            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
         }
         return hipGetLastError();
     };
     if (out_stats) {
         unsigned long long* d_cnt = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_cnt, 9 * sizeof(unsigned long long)));
-        hipError_t e = hipMemsetAsync(d_cnt, 0, 9 * sizeof(unsigned long long), stream);
+        HIP_TRY(hipMalloc((void**)&d_cnt, 16 * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_cnt, 0, 16 * sizeof(unsigned long long), stream);
         if (e == hipSuccess) e = launch(true, d_cnt);
-        unsigned long long h[9] = {0};
+        unsigned long long h[16] = {0};
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         (void)hipFree(d_cnt);
         if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
+        if (std::getenv("RTM_DIAG") && h[9])
+            std::fprintf(stderr, "[rtm diag] S rounds %llu (avg %.1f lanes)  T steps %llu (avg %.1f lanes)\n", h[9], (double)h[10] / (double)h[9], h[11],
+                         h[11] ? (double)h[12] / (double)h[11] : 0.0);
         out_stats->rays_camera = h[0]; out_stats->rays_bounce = h[1]; out_stats->rays_shadow = h[2];
         out_stats->sphere_tests = h[3]; out_stats->plane_tests = h[4]; out_stats->bbox_tests = h[5];
         out_stats->cells_visited = h[6]; out_stats->tri_tests = h[7]; out_stats->model_hits = h[8];

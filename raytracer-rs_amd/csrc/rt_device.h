@@ -26,8 +26,16 @@ constexpr uint32_t kNoId = 0xFFFFFFFFu;
 struct V3 {
     double x, y, z;
 };
+// Pointers read out of RtmDevModel records are generic to the compiler (it would emit flat_load, which also
+// ties up the LDS counter); they always point into HBM, so say so.
+template <typename T>
+using gptr = const T __attribute__((address_space(1)))*;
+template <typename T>
+RTM_DEV gptr<T> as_global(const T* p) { return (gptr<T>)p; }
+
 RTM_DEV V3 mk(double x, double y, double z) { return V3{x, y, z}; }
 RTM_DEV V3 ld3(const double* p) { return V3{p[0], p[1], p[2]}; }
+RTM_DEV V3 ld3(gptr<double> p) { return V3{p[0], p[1], p[2]}; }
 RTM_DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 RTM_DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 RTM_DEV V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
@@ -108,14 +116,16 @@ RTM_DEV bool model_intersect(const RtmDevModel& M, V3 o, V3 d, double& t_out, ui
     bool have = false;
     double best_t = 0.0;
     uint32_t best_i = 0;
+    const gptr<uint32_t> cell_start = as_global(M.cell_start), tri_idx = as_global(M.tri_idx);
+    const gptr<double> tri_pos = as_global(M.tri_pos);
     while ((unsigned)ix < (unsigned)n && (unsigned)iy < (unsigned)n && (unsigned)iz < (unsigned)n) {
         if (STATS) cnt.v[C_CELLS]++;
         const uint32_t cell = ((uint32_t)iz * (uint32_t)n + (uint32_t)iy) * (uint32_t)n + (uint32_t)ix;
-        const uint32_t k_begin = M.cell_start[cell], k_end = M.cell_start[cell + 1];  // [start, end)
+        const uint32_t k_begin = cell_start[cell], k_end = cell_start[cell + 1];  // [start, end)
         for (uint32_t k = k_begin; k < k_end; ++k) {
-            const uint32_t ti = M.tri_idx[k];
+            const uint32_t ti = tri_idx[k];
             if (STATS) cnt.v[C_TRI]++;
-            const double* tp = M.tri_pos + (size_t)ti * 9;
+            const gptr<double> tp = tri_pos + (size_t)ti * 9;
             const V3 v0 = ld3(tp), v1 = ld3(tp + 3), v2 = ld3(tp + 6);
             // model.rs:45-72
             const V3 e1 = v1 - v0, e2 = v2 - v0;
@@ -153,8 +163,8 @@ RTM_DEV bool model_intersect(const RtmDevModel& M, V3 o, V3 d, double& t_out, ui
 
 // model.rs:18-39 at hit_point = ray.at(t)  (core.rs:169-177)
 RTM_DEV V3 model_normal(const RtmDevModel& M, uint32_t ti, V3 point) {
-    const double* tp = M.tri_pos + (size_t)ti * 9;
-    const double* np = M.tri_nrm + (size_t)ti * 9;
+    const gptr<double> tp = as_global(M.tri_pos) + (size_t)ti * 9;
+    const gptr<double> np = as_global(M.tri_nrm) + (size_t)ti * 9;
     const V3 v0 = ld3(tp), v1 = ld3(tp + 3), v2 = ld3(tp + 6);
     const V3 s0 = v1 - v0, s1 = v2 - v0, s2 = point - v0;
     const double d00 = dot(s0, s0), d01 = dot(s0, s1), d11 = dot(s1, s1), d20 = dot(s2, s0), d21 = dot(s2, s1);

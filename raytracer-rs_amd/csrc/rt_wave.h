@@ -24,9 +24,12 @@
 namespace rtw {
 using namespace rtd;
 
+#ifndef RTM_WAVE_OCC
+#define RTM_WAVE_OCC 2  // waves per SIMD the register allocator must leave room for (f64 state is register-hungry)
+#endif
 constexpr int kOccLdsWords = 8192;  // 32 KiB of LDS for occupancy bitmaps (8 models of 32^3 cells)
 
-enum : uint32_t { ST_CONSUME = 0, ST_ENTER = 1, ST_TRAV = 2, ST_DEAD = 3 };
+enum : uint32_t { ST_CONSUME = 0, ST_ENTER = 1, ST_TRAV = 2, ST_DEAD = 3, ST_FETCH = 4 };
 enum : uint32_t { PH_START = 0, PH_PATH = 1, PH_SHADOW = 2 };
 
 struct RenderArgsW {
@@ -35,10 +38,12 @@ struct RenderArgsW {
     uint32_t row_begin, row_stride, n_rows, flags;
     uint32_t s_threshold;  // run an S round when at least this many lanes wait (or nobody traverses)
     uint32_t t_min_lanes;  // leave the T loop when fewer lanes than this still traverse and some lane waits
+    uint32_t tiles_x, n_tiles;  // 8x8 pixel tiles over width x n_rows; pixel ids are tile-major
+    uint32_t* work_counter;     // zeroed before the launch: next unclaimed 64-pixel chunk (persistent fetch)
 };
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderArgsW A, double* __restrict__ out_rgb,
+__global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevScene S, RenderArgsW A, double* __restrict__ out_rgb,
                                                            uint32_t* __restrict__ out_obj, uint32_t* __restrict__ out_tri,
                                                            unsigned long long* __restrict__ out_cnt) {
     __shared__ uint32_t occ_lds[kOccLdsWords];
@@ -49,28 +54,27 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
             const uint32_t n = S.models[m].n;
             const uint32_t words = (n * n * n + 31u) >> 5;
             if (base + words > (uint32_t)kOccLdsWords) break;
-            const uint32_t* src = S.models[m].occupancy;
+            const gptr<uint32_t> src = as_global(S.models[m].occupancy);
             for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) occ_lds[base + i] = src[i];
             base += words;
         }
     }
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t ly = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63u;
     Counters cnt;
     if (STATS)
         for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
-
-    const bool live = x < A.W && ly < A.n_rows;
-    const uint32_t y = A.row_begin + ly * A.row_stride;
-    const uint32_t pixel = x + A.W * y;  // main.rs:160-161,177
+    // Persistent lanes: a lane that finishes its pixel claims the next one from the wave's pool, which the wave
+    // refills 64 pixels (one 8x8 tile) at a time with one atomic.  Any lane may render any pixel because a pixel's
+    // samples are summed by the lane that owns it (main.rs:169), so results do not depend on the schedule.
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+    uint32_t x = 0, ly = 0, y = 0, pixel = 0;
     const double n_spp = (double)A.spp;
     const int K = (int)A.max_bounces;
 
     // ---- lane state ------------------------------------------------------------------------------
-    uint32_t st = live ? ST_CONSUME : ST_DEAD;
+    uint32_t st = ST_FETCH;
     uint32_t phase = PH_START, s = 0, li = 0, mat = 0, model_i = 0;
     int bounce = 0;
     V3 px = mk(0, 0, 0), color = mk(0, 0, 0);
@@ -98,12 +102,49 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
         }
     };
 
+    uint64_t dg_s_rounds = 0, dg_s_lanes = 0, dg_t_steps = 0, dg_t_lanes = 0;  // scheduler diagnostics (STATS build only)
     for (;;) {
+        // ---- hand out pixels to idle lanes
+        for (;;) {
+            const unsigned long long need = __ballot(st == ST_FETCH);
+            if (!need) break;
+            if (pool_next == pool_end) {
+                uint32_t base = 0;
+                if (lane == (uint32_t)(__ffsll((long long)need) - 1)) base = atomicAdd(A.work_counter, 1u);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)need) - 1);
+                if (base >= A.n_tiles) {  // frame exhausted
+                    if (st == ST_FETCH) st = ST_DEAD;
+                    break;
+                }
+                pool_next = base * 64u;
+                pool_end = pool_next + 64u;
+            }
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t avail = pool_end - pool_next;
+            if (st == ST_FETCH && rank < avail) {
+                const uint32_t id = pool_next + rank, tile = id >> 6, in = id & 63u;
+                x = (tile % A.tiles_x) * 8u + (in & 7u);
+                ly = (tile / A.tiles_x) * 8u + (in >> 3);
+                if (x < A.W && ly < A.n_rows) {  // ragged right / bottom tiles: ids outside the image are skipped
+                    y = A.row_begin + ly * A.row_stride;
+                    pixel = x + A.W * y;  // main.rs:160-161,177
+                    px = mk(0, 0, 0);
+                    s = 0;
+                    phase = PH_START;
+                    st = ST_CONSUME;
+                }
+            }
+            const uint32_t want = (uint32_t)__popcll(need);
+            pool_next += want < avail ? want : avail;
+        }
         const unsigned long long waiting = __ballot(st == ST_CONSUME || st == ST_ENTER);
         const unsigned long long traversing = __ballot(st == ST_TRAV);
         if (!waiting && !traversing) break;
-        if (!traversing || (uint32_t)__popcll(waiting) >= A.s_threshold) {
+        const uint32_t live = (uint32_t)__popcll(waiting | traversing);
+        const uint32_t s_need = (A.s_threshold * live + 63u) >> 6;  // thresholds are per 64 live lanes
+        if (!traversing || (uint32_t)__popcll(waiting) >= s_need) {
             // =========================== S round ===========================
+            if (STATS) { dg_s_rounds++; dg_s_lanes += (uint64_t)__popcll(waiting); }
             if (st == ST_CONSUME) {
                 bool gen = false, finish = false, end_sample = false;
                 if (phase == PH_PATH) {
@@ -181,7 +222,7 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
                         out_rgb[oi * 3 + 2] = px.z;
                         if (out_obj) out_obj[oi] = obj0;
                         if (out_tri) out_tri[oi] = tri0;
-                        st = ST_DEAD;
+                        st = ST_FETCH;
                     } else {
                         gen = true;
                     }
@@ -200,7 +241,7 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
                     bounce = 0;
                     phase = PH_PATH;
                 }
-                if (st != ST_DEAD) {
+                if (st != ST_FETCH) {
                     // ---- new query: analytic primitives (core.rs:183-210)
                     if (STATS && phase == PH_PATH) cnt.v[bounce == 0 ? C_CAM : C_BOUNCE]++;
                     best = __builtin_inf();
@@ -283,12 +324,13 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
             }
             const RtmDevModel& M = S.models[mm];
             const uint32_t n = M.n;
-            const uint32_t* __restrict__ cell_start = M.cell_start;
-            const uint32_t* __restrict__ tri_idx = M.tri_idx;
-            const double* __restrict__ tri_pos = M.tri_pos;
-            const uint32_t* __restrict__ occ_glb = M.occupancy;
+            const gptr<uint32_t> cell_start = as_global(M.cell_start), tri_idx = as_global(M.tri_idx);
+            const gptr<double> tri_pos = as_global(M.tri_pos);
+            const gptr<uint32_t> occ_glb = as_global(M.occupancy);
+            const bool occ_in_lds = occ_base != 0xFFFFFFFFu;
             for (;;) {
                 const bool mine = st == ST_TRAV && model_i == mm;
+                if (STATS) { dg_t_steps++; dg_t_lanes += (uint64_t)__popcll(__ballot(mine)); }
                 if (mine) {
                     if (k >= k_end) {  // current cell exhausted (or first cell)
                         if (have) {    // core.rs:147-149: first cell with any accepted hit ends the walk
@@ -312,7 +354,9 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
                                 if (!inside) break;
                                 if (STATS) cnt.v[C_CELLS]++;
                                 const uint32_t cell = ((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix;
-                                const uint32_t word = occ_base != 0xFFFFFFFFu ? occ_lds[occ_base + (cell >> 5)] : occ_glb[cell >> 5];
+                                uint32_t word;
+                                if (occ_in_lds) word = occ_lds[occ_base + (cell >> 5)];
+                                else word = occ_glb[cell >> 5];
                                 if ((word >> (cell & 31u)) & 1u) {
                                     k = cell_start[cell];
                                     k_end = cell_start[cell + 1];
@@ -334,7 +378,7 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
                         const uint32_t ti = tri_idx[k];
                         ++k;
                         if (STATS) cnt.v[C_TRI]++;
-                        const double* tp = tri_pos + (size_t)ti * 9;
+                        const gptr<double> tp = tri_pos + (size_t)ti * 9;
                         const V3 v0 = ld3(tp), v1 = ld3(tp + 3), v2 = ld3(tp + 6);
                         const V3 e1 = v1 - v0, e2 = v2 - v0;
                         const V3 p = cross(d, e2);
@@ -361,7 +405,7 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
                 const unsigned long long still = __ballot(st == ST_TRAV && model_i == mm);
                 if (!still) break;
                 const unsigned long long w2 = __ballot(st == ST_CONSUME || st == ST_ENTER);
-                if ((uint32_t)__popcll(still) < A.t_min_lanes && (uint32_t)__popcll(w2) >= A.s_threshold) break;
+                if ((uint32_t)__popcll(still) * 64u < A.t_min_lanes * live && (uint32_t)__popcll(w2) >= s_need) break;
             }
         }
     }
@@ -375,6 +419,12 @@ __global__ __launch_bounds__(256) void render_wave_kernel(RtmDevScene S, RenderA
                 v += ((uint64_t)hi << 32) | lo;
             }
             if (lane == 0 && v) atomicAdd(out_cnt + i, (unsigned long long)v);
+        }
+        if (lane == 0) {
+            atomicAdd(out_cnt + 9, (unsigned long long)dg_s_rounds);
+            atomicAdd(out_cnt + 10, (unsigned long long)dg_s_lanes);
+            atomicAdd(out_cnt + 11, (unsigned long long)dg_t_steps);
+            atomicAdd(out_cnt + 12, (unsigned long long)dg_t_lanes);
         }
     }
 }
