@@ -163,6 +163,7 @@ __global__ void deinterleave_kernel(const double* __restrict__ blocks, uint32_t 
 struct rtm_scene_dev {
     RtmDevScene view;
     std::vector<void*> allocs;
+    std::vector<uint32_t> occ_words;  // per model: words of its cell-occupancy bitmap
     int device;
 };
 
@@ -342,10 +343,15 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             if (start[c + 1] > start[c]) occ[c >> 5] |= 1u << (c & 31);
         }
         start[n3 + 1] = start[n3];
+        sd->occ_words.push_back((uint32_t)occ.size());
         std::vector<uint32_t> idx(M.tri_idx, M.tri_idx + M.n_tri_idx);
         std::vector<double> pos((size_t)M.n_tris * 9), nrm((size_t)M.n_tris * 9);
         for (uint32_t t = 0; t < M.n_tris; ++t)
-            for (int a = 0; a < 9; ++a) { pos[(size_t)t * 9 + a] = M.pos[a][t]; nrm[(size_t)t * 9 + a] = M.nrm[a][t]; }
+            for (int a = 0; a < 9; ++a) {
+                // v0, then the edges v1-v0 and v2-v0: the same IEEE subtraction the reference performs per test
+                pos[(size_t)t * 9 + a] = a < 3 ? M.pos[a][t] : M.pos[a][t] - M.pos[a % 3][t];
+                nrm[(size_t)t * 9 + a] = M.nrm[a][t];
+            }
         if ((rc = upload(sd, start, &D.cell_start)) || (rc = upload(sd, idx, &D.tri_idx)) || (rc = upload(sd, pos, &D.tri_pos)) ||
             (rc = upload(sd, nrm, &D.tri_nrm)) || (rc = upload(sd, occ, &D.occupancy)))
             return fail(rc);
@@ -373,7 +379,16 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     const bool v1 = (p->flags & RTM_FLAG_KERNEL_V1) != 0;
     RenderArgs A{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags};
     rtw::RenderArgsW AW{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags,
-                        g_s_threshold, g_t_min_lanes, (p->width + 7) / 8, ((p->width + 7) / 8) * ((n_rows + 7) / 8), g_work_counter};
+                        g_s_threshold, g_t_min_lanes, (p->width + 7) / 8, ((p->width + 7) / 8) * ((n_rows + 7) / 8), 0u, g_work_counter};
+    {   // occupancy bitmaps that fit the LDS budget, models in order (same rule as the kernel's staging loop)
+        uint32_t words = 0;
+        for (uint32_t w : sd->occ_words) {
+            if (words + w > (uint32_t)rtw::kOccLdsWordsMax) break;
+            words += w;
+        }
+        AW.occ_words = words;
+    }
+    const size_t wave_lds = (size_t)rtw::kColdBytes + (size_t)AW.occ_words * 4;
     // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; each wave claims 8x8 tiles
     static const uint32_t wgs_per_cu = std::getenv("RTM_WGS_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("RTM_WGS_PER_CU"))) : 4u;
     const uint32_t wave_wgs = std::min<uint32_t>((AW.n_tiles + 3) / 4, (uint32_t)g_num_cus * wgs_per_cu);
@@ -384,8 +399,8 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         } else {
             hipError_t me = hipMemsetAsync(g_work_counter, 0, 256, stream);  // claimed tiles start at 0 every frame
             if (me != hipSuccess) return me;
-            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, 0, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
         }
         return hipGetLastError();
     };

@@ -126,9 +126,8 @@ RTM_DEV bool model_intersect(const RtmDevModel& M, V3 o, V3 d, double& t_out, ui
             const uint32_t ti = tri_idx[k];
             if (STATS) cnt.v[C_TRI]++;
             const gptr<double> tp = tri_pos + (size_t)ti * 9;
-            const V3 v0 = ld3(tp), v1 = ld3(tp + 3), v2 = ld3(tp + 6);
-            // model.rs:45-72
-            const V3 e1 = v1 - v0, e2 = v2 - v0;
+            // model.rs:45-72; the record holds v0 and the two edges v1-v0, v2-v0 (model.rs:46-47 evaluated at upload)
+            const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
             const V3 p = cross(d, e2);
             const double det = dot(e1, p);
             if (fabs(det) < kF64Eps) continue;
@@ -165,8 +164,7 @@ RTM_DEV bool model_intersect(const RtmDevModel& M, V3 o, V3 d, double& t_out, ui
 RTM_DEV V3 model_normal(const RtmDevModel& M, uint32_t ti, V3 point) {
     const gptr<double> tp = as_global(M.tri_pos) + (size_t)ti * 9;
     const gptr<double> np = as_global(M.tri_nrm) + (size_t)ti * 9;
-    const V3 v0 = ld3(tp), v1 = ld3(tp + 3), v2 = ld3(tp + 6);
-    const V3 s0 = v1 - v0, s1 = v2 - v0, s2 = point - v0;
+    const V3 v0 = ld3(tp), s0 = ld3(tp + 3), s1 = ld3(tp + 6), s2 = point - v0;  // s0 = v1-v0, s1 = v2-v0 (model.rs:20-21)
     const double d00 = dot(s0, s0), d01 = dot(s0, s1), d11 = dot(s1, s1), d20 = dot(s2, s0), d21 = dot(s2, s1);
     const double den = d00 * d11 - d01 * d01;
     const double v = (d11 * d20 - d01 * d21) / den;

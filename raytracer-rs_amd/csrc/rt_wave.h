@@ -1,19 +1,26 @@
 // rt_wave.h -- the production render kernel: a wave-scheduled path-state machine for gfx950.
 //
 // Why this shape (DESIGN.md "Kernel"): the per-ray arithmetic is fixed by bit parity with the reference, so
-// throughput is decided by how many of a wavefront's 64 lanes do useful work per issued f64 instruction.
+// throughput is decided by (a) how many of a wavefront's 64 lanes do useful work per issued f64 instruction
+// and (b) how many wavefronts a SIMD can hold to cover L2 latency and the long f64 divide/sqrt chains.
 // A straight transliteration of cast()/hit() (rt_device.h, kept as the `v1` kernel) runs at ~10 % lane
 // utilisation on the bunny scene: shadow rays, bounce rays and the 3D-DDA sit at different code addresses
-// and every DDA loop runs for the slowest lane.  Here every lane owns one pixel and walks the reference's
-// sequence   camera ray -> hit -> [shadow ray per light] -> bounce -> ...   (main.rs:57-132,159-170) as a
-// state machine with exactly ONE copy of each expensive block, and the wave alternates between
-//   S  "shade/set-up": consume the finished query, produce the next ray, analytic primitives, slab test,
-//                      DDA initialisation (core.rs:68-125, main.rs:65-125), run for all waiting lanes at once;
-//   T  "traverse"    : one triangle test per traversing lane per step, cell advance folded in
-//                      (core.rs:129-167, model.rs:43-74),
-// chosen per iteration from wave ballots (popcount thresholds), so lanes finishing a short DDA wait only
-// until enough lanes are ready for the next S round.  Empty cells are skipped through a cell-occupancy
-// bitmap staged in LDS (one bit per cell, derived from the offset array at upload time).
+// and every DDA loop runs for the slowest lane.  Here
+//   * every lane owns one pixel at a time and walks the reference's sequence
+//       camera ray -> hit -> [shadow ray per light] -> bounce -> ...      (main.rs:57-132,159-170)
+//     as a state machine with exactly ONE copy of each expensive block;
+//   * the wave alternates, by ballot/popcount thresholds, between
+//       S "shade/set-up": consume the finished query, produce the next ray, analytic primitives, slab test,
+//                         DDA initialisation (core.rs:68-125, main.rs:65-125) for all waiting lanes at once,
+//       T "traverse"    : one triangle test per traversing lane per step, cell advance folded in
+//                         (core.rs:129-167, model.rs:43-74);
+//   * lanes are persistent: a lane that finishes its pixel claims the next one (8x8 tiles handed to waves by
+//     one atomic each), so there is no tail of idle lanes inside a wave;
+//   * per-lane state that only the S round touches (pixel/sample accumulators, shading normal, bounce
+//     direction, diffuse sum) lives in LDS, not VGPRs: the T loop then fits the register budget of
+//     RTM_WAVE_OCC waves per SIMD;
+//   * empty cells are skipped through a cell-occupancy bitmap staged in LDS (one bit per cell, derived from
+//     the offset array at upload time) -- the same DDA walk, without touching the lists.
 // The arithmetic of every block is the same op sequence as rt_device.h / the reference: results are
 // bit-identical, which tests/test_parity_gpu.py checks for both kernels.
 #pragma once
@@ -25,82 +32,100 @@ namespace rtw {
 using namespace rtd;
 
 #ifndef RTM_WAVE_OCC
-#define RTM_WAVE_OCC 2  // waves per SIMD the register allocator must leave room for (f64 state is register-hungry)
+#define RTM_WAVE_OCC 4  // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int kOccLdsWords = 8192;  // 32 KiB of LDS for occupancy bitmaps (8 models of 32^3 cells)
+constexpr int kBlock = 256;
+constexpr int kColdFields = 17;                       // doubles of S-only state per lane, see enum below
+constexpr int kColdBytes = kColdFields * kBlock * 8;  // 34,816 B per workgroup
+constexpr int kOccLdsWordsMax = 8192;                 // at most 32 KiB of bitmaps in LDS; the rest stay in HBM
 
 enum : uint32_t { ST_CONSUME = 0, ST_ENTER = 1, ST_TRAV = 2, ST_DEAD = 3, ST_FETCH = 4 };
 enum : uint32_t { PH_START = 0, PH_PATH = 1, PH_SHADOW = 2 };
+enum : int { F_PX = 0, F_COLOR = 3, F_ATT = 6, F_NRM = 7, F_BD = 10, F_DIFF = 13, F_DL2 = 16 };
 
 struct RenderArgsW {
     uint32_t W, H, spp, max_bounces;
     uint64_t seed;
     uint32_t row_begin, row_stride, n_rows, flags;
-    uint32_t s_threshold;  // run an S round when at least this many lanes wait (or nobody traverses)
-    uint32_t t_min_lanes;  // leave the T loop when fewer lanes than this still traverse and some lane waits
+    uint32_t s_threshold;  // per 64 live lanes: run an S round when at least this many wait (or nobody traverses)
+    uint32_t t_min_lanes;  // per 64 live lanes: leave the T loop below this many traversing lanes (if S is due)
     uint32_t tiles_x, n_tiles;  // 8x8 pixel tiles over width x n_rows; pixel ids are tile-major
-    uint32_t* work_counter;     // zeroed before the launch: next unclaimed 64-pixel chunk (persistent fetch)
+    uint32_t occ_words;         // bitmap words staged in LDS (models in order, as many as fit)
+    uint32_t* work_counter;     // zeroed before the launch: next unclaimed tile (persistent fetch)
 };
 
 template <bool STATS>
-__global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevScene S, RenderArgsW A, double* __restrict__ out_rgb,
-                                                           uint32_t* __restrict__ out_obj, uint32_t* __restrict__ out_tri,
-                                                           unsigned long long* __restrict__ out_cnt) {
-    __shared__ uint32_t occ_lds[kOccLdsWords];
-    // ---- stage the occupancy bitmaps (models are laid out back to back; those that do not fit stay in HBM)
+__global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDevScene S, RenderArgsW A, double* __restrict__ out_rgb,
+                                                                            uint32_t* __restrict__ out_obj, uint32_t* __restrict__ out_tri,
+                                                                            unsigned long long* __restrict__ out_cnt) {
+    extern __shared__ double lds_raw[];
+    double* const cold = lds_raw;                                          // [kColdFields][kBlock]
+    uint32_t* const occ_lds = reinterpret_cast<uint32_t*>(lds_raw + kColdFields * kBlock);  // [A.occ_words]
+    const uint32_t tid = threadIdx.x;
+    auto ldc = [&](int f) -> double { return cold[f * kBlock + tid]; };
+    auto stc = [&](int f, double v) { cold[f * kBlock + tid] = v; };
+    auto ldc3 = [&](int f) -> V3 { return mk(ldc(f), ldc(f + 1), ldc(f + 2)); };
+    auto stc3 = [&](int f, V3 v) { stc(f, v.x); stc(f + 1, v.y); stc(f + 2, v.z); };
+
+    // ---- stage the occupancy bitmaps (models back to back; those that do not fit stay in HBM)
     {
         uint32_t base = 0;
         for (uint32_t m = 0; m < S.n_models; ++m) {
             const uint32_t n = S.models[m].n;
             const uint32_t words = (n * n * n + 31u) >> 5;
-            if (base + words > (uint32_t)kOccLdsWords) break;
+            if (base + words > A.occ_words) break;
             const gptr<uint32_t> src = as_global(S.models[m].occupancy);
-            for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) occ_lds[base + i] = src[i];
+            for (uint32_t i = tid; i < words; i += kBlock) occ_lds[base + i] = src[i];
             base += words;
         }
     }
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = tid & 63u;
     Counters cnt;
     if (STATS)
         for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
-    // Persistent lanes: a lane that finishes its pixel claims the next one from the wave's pool, which the wave
-    // refills 64 pixels (one 8x8 tile) at a time with one atomic.  Any lane may render any pixel because a pixel's
-    // samples are summed by the lane that owns it (main.rs:169), so results do not depend on the schedule.
-    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
-    uint32_t x = 0, ly = 0, y = 0, pixel = 0;
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: the wave's claimed tile
     const double n_spp = (double)A.spp;
     const int K = (int)A.max_bounces;
 
-    // ---- lane state ------------------------------------------------------------------------------
-    uint32_t st = ST_FETCH;
-    uint32_t phase = PH_START, s = 0, li = 0, mat = 0, model_i = 0;
+    // ---- hot lane state (VGPRs) ---------------------------------------------------------------------
+    uint32_t st = ST_FETCH, phase = PH_START;
+    uint32_t x = 0, ly = 0, pixel = 0, s = 0, li = 0, model_i = 0, mat = 0;  // mat: material of the surface being shaded
     int bounce = 0;
-    V3 px = mk(0, 0, 0), color = mk(0, 0, 0);
-    double att = 1.0;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);        // current query ray
-    V3 P = mk(0, 0, 0), nrm = mk(0, 0, 0), bd = mk(0, 0, 0), diffuse = mk(0, 0, 0);
-    double dl2 = 0.0;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);  // current query ray; during shadow queries o is the shaded point P
     uint32_t obj0 = kNoId, tri0 = kNoId;
-    // query result so far (core.rs:69-85)
-    double best = 0.0;
+    double best = 0.0;                    // query result so far (core.rs:69-85)
     bool found = false;
-    uint32_t h_obj = kNoId, h_tri = kNoId, h_mat = 0, h_kind = 0, h_prim = 0;
-    // traversal state (core.rs:99-128)
-    int ix = 0, iy = 0, iz = 0, sx = 1, sy = 1, sz = 1;
+    uint32_t h_obj = kNoId, h_tri = kNoId, h_mat = 0, h_kp = 0;  // h_kp = kind << 30 | prim
+    int ix = 0, iy = 0, iz = 0;           // traversal state (core.rs:99-128)
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
     uint32_t k = 0, k_end = 0, m_tri = 0;
     double m_t = 0.0;
     bool have = false, fresh = false;
 
-    auto consider = [&](double t, uint32_t obj, uint32_t mt, uint32_t kind, uint32_t prim, uint32_t tri) {
-        if (t <= kEps) return;  // core.rs:75-77
+    auto consider = [&](double t, uint32_t obj, uint32_t mt, uint32_t kp, uint32_t tri) {
+        if (t <= kEps) return;                                  // core.rs:75-77
         if (t < best || (found && t == best && obj < h_obj)) {  // core.rs:79, ties to the earlier object
             best = t; found = true;
-            h_obj = obj; h_mat = mt; h_kind = kind; h_prim = prim; h_tri = tri;
+            h_obj = obj; h_mat = mt; h_kp = kp; h_tri = tri;
         }
     };
+    // core.rs:151-167 with the step signs of core.rs:102-104.  Written with selects, not branches: hipcc turns the
+    // branchy form into an indexed update of a stack array {ix,iy,iz}/{tmx,tmy,tmz}, i.e. scratch traffic per cell.
+#define RTW_DDA_ADVANCE()                                                      \
+    do {                                                                       \
+        const bool ax_ = (tmx < tmy) && (tmx < tmz);                           \
+        const bool ay_ = !(tmx < tmy) && (tmy < tmz);                          \
+        const bool az_ = !ax_ && !ay_;                                         \
+        ix += ax_ ? (d.x > 0.0 ? 1 : -1) : 0;                                  \
+        iy += ay_ ? (d.y > 0.0 ? 1 : -1) : 0;                                  \
+        iz += az_ ? (d.z > 0.0 ? 1 : -1) : 0;                                  \
+        const double nx_ = tmx + tdx, ny_ = tmy + tdy, nz_ = tmz + tdz;        \
+        tmx = ax_ ? nx_ : tmx;                                                 \
+        tmy = ay_ ? ny_ : tmy;                                                 \
+        tmz = az_ ? nz_ : tmz;                                                 \
+    } while (0)
 
     uint64_t dg_s_rounds = 0, dg_s_lanes = 0, dg_t_steps = 0, dg_t_lanes = 0;  // scheduler diagnostics (STATS build only)
     for (;;) {
@@ -109,9 +134,10 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
             const unsigned long long need = __ballot(st == ST_FETCH);
             if (!need) break;
             if (pool_next == pool_end) {
+                const int first = __ffsll((long long)need) - 1;
                 uint32_t base = 0;
-                if (lane == (uint32_t)(__ffsll((long long)need) - 1)) base = atomicAdd(A.work_counter, 1u);
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)need) - 1);
+                if (lane == (uint32_t)first) base = atomicAdd(A.work_counter, 1u);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
                 if (base >= A.n_tiles) {  // frame exhausted
                     if (st == ST_FETCH) st = ST_DEAD;
                     break;
@@ -125,10 +151,9 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                 const uint32_t id = pool_next + rank, tile = id >> 6, in = id & 63u;
                 x = (tile % A.tiles_x) * 8u + (in & 7u);
                 ly = (tile / A.tiles_x) * 8u + (in >> 3);
-                if (x < A.W && ly < A.n_rows) {  // ragged right / bottom tiles: ids outside the image are skipped
-                    y = A.row_begin + ly * A.row_stride;
-                    pixel = x + A.W * y;  // main.rs:160-161,177
-                    px = mk(0, 0, 0);
+                if (x < A.W && ly < A.n_rows) {  // ids outside a ragged right/bottom tile are skipped
+                    pixel = x + A.W * (A.row_begin + ly * A.row_stride);  // main.rs:160-161,177
+                    stc3(F_PX, mk(0, 0, 0));
                     s = 0;
                     phase = PH_START;
                     st = ST_CONSUME;
@@ -141,79 +166,81 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
         const unsigned long long traversing = __ballot(st == ST_TRAV);
         if (!waiting && !traversing) break;
         const uint32_t live = (uint32_t)__popcll(waiting | traversing);
-        const uint32_t s_need = (A.s_threshold * live + 63u) >> 6;  // thresholds are per 64 live lanes
+        const uint32_t s_need = (A.s_threshold * live + 63u) >> 6;
         if (!traversing || (uint32_t)__popcll(waiting) >= s_need) {
             // =========================== S round ===========================
             if (STATS) { dg_s_rounds++; dg_s_lanes += (uint64_t)__popcll(waiting); }
             if (st == ST_CONSUME) {
-                bool gen = false, finish = false, end_sample = false;
+                bool gen = false, finish = false, end_sample = false, next_shadow = false;
                 if (phase == PH_PATH) {
                     if (bounce == 0 && s == 0) { obj0 = found ? h_obj : kNoId; tri0 = found ? h_tri : kNoId; }
                     if (!found) {
-                        color = color + mk(1, 1, 1) * att;  // main.rs:127
+                        stc3(F_COLOR, ldc3(F_COLOR) + mk(1, 1, 1) * ldc(F_ATT));  // main.rs:127
                         end_sample = true;
                     } else {
-                        P = ray_at(o, d, best);  // core.rs:89
+                        const V3 P = ray_at(o, d, best);  // core.rs:89
+                        const uint32_t kind = h_kp >> 30, prim = h_kp & 0x3FFFFFFFu;
                         V3 nn;
-                        if (h_kind == 0u) nn = normalize(ray_at(o, d, best) - ld3(S.spheres + (size_t)h_prim * 4));  // core.rs:195
-                        else if (h_kind == 1u) nn = ld3(S.planes + (size_t)h_prim * 4);                              // core.rs:209
-                        else nn = model_normal(S.models[h_prim], h_tri, P);                                          // core.rs:169-177
+                        if (kind == 0u) nn = normalize(ray_at(o, d, best) - ld3(S.spheres + (size_t)prim * 4));  // core.rs:195
+                        else if (kind == 1u) nn = ld3(S.planes + (size_t)prim * 4);                              // core.rs:209
+                        else nn = model_normal(S.models[prim], h_tri, P);                                        // core.rs:169-177
                         if (dot(d, nn) > 0.001) nn = nn * -1.0;  // main.rs:68-73
-                        nrm = nn;
                         mat = h_mat;
-                        const bool metal = S.materials[(size_t)mat * 4 + 3] != 0.0;
-                        if (metal) {
-                            bd = d - nn * 2.0 * dot(d, nn);  // vec3.rs:172-175
+                        V3 bdir;
+                        if (S.materials[(size_t)mat * 4 + 3] != 0.0) {
+                            bdir = d - nn * 2.0 * dot(d, nn);  // vec3.rs:172-175 (metal)
                         } else {
                             uint32_t ra[4], rb[4];
                             philox(A.seed, pixel, s, 1u + 2u * (uint32_t)bounce, ra);
                             philox(A.seed, pixel, s, 2u + 2u * (uint32_t)bounce, rb);
                             const V3 rnd = mk(u01(ra[0], ra[1]) * (1.0 - 0.0) + 0.0, u01(ra[2], ra[3]) * (1.0 - 0.0) + 0.0,
                                               u01(rb[0], rb[1]) * (1.0 - 0.0) + 0.0);
-                            bd = normalize(nn + rnd);  // main.rs:53
+                            bdir = normalize(nn + rnd);  // main.rs:53
                         }
-                        diffuse = mk(0, 0, 0);
+                        stc3(F_NRM, nn);
+                        stc3(F_BD, bdir);
+                        stc3(F_DIFF, mk(0, 0, 0));
+                        o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
                         li = 0;
-                        if (S.n_lights == 0u) finish = true;
+                        if (S.n_lights == 0u) finish = true; else next_shadow = true;
                     }
-                } else if (phase == PH_SHADOW) {  // main.rs:86-104 for light li
+                } else if (phase == PH_SHADOW) {  // main.rs:86-104 for light li; o == P
                     const double* L = S.lights + (size_t)li * 8;
+                    const double dl2 = ldc(F_DL2);
                     bool occluded = false;
-                    if (found) occluded = sqdist(ray_at(o, d, best), P) <= dl2;
+                    if (found) occluded = sqdist(ray_at(o, d, best), o) <= dl2;
                     if (!occluded) {
-                        const double eff = dot(d, nrm);
+                        const double eff = dot(d, ldc3(F_NRM));
                         if (eff > 0.001) {
                             const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
                             const double decay = 1.0 / dd;
-                            diffuse = diffuse + ld3(L + 3) * decay * eff;
+                            stc3(F_DIFF, ldc3(F_DIFF) + ld3(L + 3) * decay * eff);
                         }
                     }
                     ++li;
-                    if (li >= S.n_lights) finish = true;
+                    if (li >= S.n_lights) finish = true; else next_shadow = true;
                 } else {
                     gen = true;
                 }
                 if (finish) {  // main.rs:107-125
                     const double* mp = S.materials + (size_t)mat * 4;
                     const bool metal = mp[3] != 0.0;
-                    color = color + ld3(mp) * att * (diffuse * (metal ? 0.2 : 0.9));
-                    o = P;
-                    d = bd;
-                    att *= metal ? 0.8 : 0.1;
+                    const double att = ldc(F_ATT);
+                    stc3(F_COLOR, ldc3(F_COLOR) + ld3(mp) * att * (ldc3(F_DIFF) * (metal ? 0.2 : 0.9)));
+                    d = ldc3(F_BD);
+                    stc(F_ATT, att * (metal ? 0.8 : 0.1));
                     ++bounce;
                     phase = PH_PATH;
                     if (bounce >= K) end_sample = true;
-                } else if (phase != PH_START && !end_sample) {  // next shadow query (main.rs:80-85)
-                    const double* L = S.lights + (size_t)li * 8;
-                    const V3 lp = ld3(L);
-                    o = P;
-                    d = normalize(lp - P);
-                    dl2 = sqdist(P, lp);
+                } else if (next_shadow) {  // main.rs:80-85
+                    const V3 lp = ld3(S.lights + (size_t)li * 8);
+                    d = normalize(lp - o);
+                    stc(F_DL2, sqdist(o, lp));
                     phase = PH_SHADOW;
                     if (STATS) cnt.v[C_SHADOW]++;
                 }
                 if (end_sample) {
-                    px = px + color / n_spp;  // main.rs:169
+                    const V3 px = ldc3(F_PX) + ldc3(F_COLOR) / n_spp;  // main.rs:169
                     ++s;
                     if (s >= A.spp) {
                         const size_t oi = (size_t)ly * A.W + x;
@@ -224,6 +251,7 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                         if (out_tri) out_tri[oi] = tri0;
                         st = ST_FETCH;
                     } else {
+                        stc3(F_PX, px);
                         gen = true;
                     }
                 }
@@ -235,9 +263,9 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                         xo = u01(r[0], r[1]) * (0.5 - -0.5) + -0.5;
                         yo = u01(r[2], r[3]) * (0.5 - -0.5) + -0.5;
                     }
-                    camera_ray(S, x, y, A.W, A.H, xo, yo, o, d);
-                    color = mk(0, 0, 0);
-                    att = 1.0;
+                    camera_ray(S, x, A.row_begin + ly * A.row_stride, A.W, A.H, xo, yo, o, d);
+                    stc3(F_COLOR, mk(0, 0, 0));
+                    stc(F_ATT, 1.0);
                     bounce = 0;
                     phase = PH_PATH;
                 }
@@ -246,7 +274,7 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                     if (STATS && phase == PH_PATH) cnt.v[bounce == 0 ? C_CAM : C_BOUNCE]++;
                     best = __builtin_inf();
                     found = false;
-                    h_obj = kNoId; h_tri = kNoId; h_mat = 0; h_kind = 0; h_prim = 0;
+                    h_obj = kNoId; h_tri = kNoId; h_kp = 0;
                     const double a = dot(d, d);
                     for (uint32_t i = 0; i < S.n_spheres; ++i) {
                         if (STATS) cnt.v[C_SPHERE]++;
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                         const double disc = b * b - 4.0 * a * c;
                         if (disc < 0.0) continue;
                         const double t = (-b - __builtin_sqrt(disc)) / (2.0 * a);
-                        consider(t, S.sph_ids[i * 2 + 1], S.sph_ids[i * 2], 0u, i, kNoId);
+                        consider(t, S.sph_ids[i * 2 + 1], S.sph_ids[i * 2], i, kNoId);
                     }
                     for (uint32_t i = 0; i < S.n_planes; ++i) {
                         if (STATS) cnt.v[C_PLANE]++;
@@ -268,58 +296,55 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                         const V3 center = pn * pp[3];
                         const double t = dot(center - o, pn) / dv;
                         if (t < kEps) continue;
-                        consider(t, S.pl_ids[i * 2 + 1], S.pl_ids[i * 2], 1u, i, kNoId);
+                        consider(t, S.pl_ids[i * 2 + 1], S.pl_ids[i * 2], (1u << 30) | i, kNoId);
                     }
                     model_i = 0;
                     st = ST_ENTER;
                 }
             }
             // ---- enter the next model whose box the ray meets (box3D.rs:64-93, core.rs:95-125); m is wave-uniform
-            {
-                for (uint32_t m = 0; m < S.n_models; ++m) {
-                    const RtmDevModel& M = S.models[m];
-                    if (st == ST_ENTER && model_i == m) {
-                        if (STATS) cnt.v[C_BBOX]++;
-                        const double fx = 1.0 / d.x, fy = 1.0 / d.y, fz = 1.0 / d.z;
-                        const double t1 = (M.bmin[0] - o.x) * fx, t2 = (M.bmax[0] - o.x) * fx;
-                        const double t3 = (M.bmin[1] - o.y) * fy, t4 = (M.bmax[1] - o.y) * fy;
-                        const double t5 = (M.bmin[2] - o.z) * fz, t6 = (M.bmax[2] - o.z) * fz;
-                        const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
-                        const double tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
-                        if (tmax < 0.0 || tmin > tmax) {
-                            model_i = m + 1;
-                        } else {
-                            const V3 P0 = ray_at(o, d, tmin);
-                            const int n = (int)M.n;
-                            ix = cell_coord((P0.x - M.bmin[0]) / M.cell[0], n);
-                            iy = cell_coord((P0.y - M.bmin[1]) / M.cell[1], n);
-                            iz = cell_coord((P0.z - M.bmin[2]) / M.cell[2], n);
-                            sx = d.x > 0.0 ? 1 : -1; sy = d.y > 0.0 ? 1 : -1; sz = d.z > 0.0 ? 1 : -1;
-                            const double nbx = (M.bmin[0] + M.hc2[0] * ((double)(ix + (sx > 0 ? 1 : 0)) + 0.5)) - M.hc[0];
-                            const double nby = (M.bmin[1] + M.hc2[1] * ((double)(iy + (sy > 0 ? 1 : 0)) + 0.5)) - M.hc[1];
-                            const double nbz = (M.bmin[2] + M.hc2[2] * ((double)(iz + (sz > 0 ? 1 : 0)) + 0.5)) - M.hc[2];
-                            tmx = (nbx - P0.x) / d.x; tmy = (nby - P0.y) / d.y; tmz = (nbz - P0.z) / d.z;
-                            tdx = ((double)sx * M.cell[0]) / d.x;
-                            tdy = ((double)sy * M.cell[1]) / d.y;
-                            tdz = ((double)sz * M.cell[2]) / d.z;
-                            have = false; fresh = true; k = 0; k_end = 0;
-                            st = ST_TRAV;
-                        }
+            for (uint32_t m = 0; m < S.n_models; ++m) {
+                const RtmDevModel& M = S.models[m];
+                if (st == ST_ENTER && model_i == m) {
+                    if (STATS) cnt.v[C_BBOX]++;
+                    const double fx = 1.0 / d.x, fy = 1.0 / d.y, fz = 1.0 / d.z;
+                    const double t1 = (M.bmin[0] - o.x) * fx, t2 = (M.bmax[0] - o.x) * fx;
+                    const double t3 = (M.bmin[1] - o.y) * fy, t4 = (M.bmax[1] - o.y) * fy;
+                    const double t5 = (M.bmin[2] - o.z) * fz, t6 = (M.bmax[2] - o.z) * fz;
+                    const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
+                    const double tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
+                    if (tmax < 0.0 || tmin > tmax) {
+                        model_i = m + 1;
+                    } else {
+                        const V3 P0 = ray_at(o, d, tmin);
+                        const int n = (int)M.n;
+                        ix = cell_coord((P0.x - M.bmin[0]) / M.cell[0], n);
+                        iy = cell_coord((P0.y - M.bmin[1]) / M.cell[1], n);
+                        iz = cell_coord((P0.z - M.bmin[2]) / M.cell[2], n);
+                        const int sx = d.x > 0.0 ? 1 : -1, sy = d.y > 0.0 ? 1 : -1, sz = d.z > 0.0 ? 1 : -1;
+                        const double nbx = (M.bmin[0] + M.hc2[0] * ((double)(ix + (sx > 0 ? 1 : 0)) + 0.5)) - M.hc[0];
+                        const double nby = (M.bmin[1] + M.hc2[1] * ((double)(iy + (sy > 0 ? 1 : 0)) + 0.5)) - M.hc[1];
+                        const double nbz = (M.bmin[2] + M.hc2[2] * ((double)(iz + (sz > 0 ? 1 : 0)) + 0.5)) - M.hc[2];
+                        tmx = (nbx - P0.x) / d.x; tmy = (nby - P0.y) / d.y; tmz = (nbz - P0.z) / d.z;
+                        tdx = ((double)sx * M.cell[0]) / d.x;
+                        tdy = ((double)sy * M.cell[1]) / d.y;
+                        tdz = ((double)sz * M.cell[2]) / d.z;
+                        have = false; fresh = true; k = 0; k_end = 0;
+                        st = ST_TRAV;
                     }
                 }
-                if (st == ST_ENTER) st = ST_CONSUME;  // no model left: the query is complete
             }
+            if (st == ST_ENTER) st = ST_CONSUME;  // no model left: the query is complete
         } else {
             // =========================== T loop ===========================
-            // all lanes traversing the same model as the first traversing lane step together (m is wave-uniform)
-            const unsigned long long trav_now = __ballot(st == ST_TRAV);
-            const int first = __ffsll((long long)trav_now) - 1;
+            // lanes traversing the same model as the first traversing lane step together (mm is wave-uniform)
+            const int first = __ffsll((long long)traversing) - 1;
             const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)model_i, first);
             uint32_t occ_base = 0;  // LDS word offset of this model's bitmap, or 0xFFFFFFFF when it stayed in HBM
             for (uint32_t j = 0; j <= mm; ++j) {
                 const uint32_t nj = S.models[j].n;
                 const uint32_t words = (nj * nj * nj + 31u) >> 5;
-                if (occ_base + words > (uint32_t)kOccLdsWords) { occ_base = 0xFFFFFFFFu; break; }
+                if (occ_base + words > A.occ_words) { occ_base = 0xFFFFFFFFu; break; }
                 if (j < mm) occ_base += words;
             }
             const RtmDevModel& M = S.models[mm];
@@ -335,19 +360,13 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                     if (k >= k_end) {  // current cell exhausted (or first cell)
                         if (have) {    // core.rs:147-149: first cell with any accepted hit ends the walk
                             if (STATS) cnt.v[C_MHIT]++;
-                            consider(m_t, M.obj, M.mat, 2u, mm, m_tri);
+                            consider(m_t, M.obj, M.mat, (2u << 30) | mm, m_tri);
                             model_i = mm + 1;
                             st = ST_ENTER;
                         } else {
-                            bool inside = true;
-                            if (!fresh) {  // core.rs:151-167
-                                if (tmx < tmy) {
-                                    if (tmx < tmz) { ix += sx; tmx += tdx; } else { iz += sz; tmz += tdz; }
-                                } else {
-                                    if (tmy < tmz) { iy += sy; tmy += tdy; } else { iz += sz; tmz += tdz; }
-                                }
-                            }
+                            if (!fresh) RTW_DDA_ADVANCE();
                             fresh = false;
+                            bool inside;
                             // skip empty cells through the occupancy bitmap: the same DDA walk, no list to scan
                             for (;;) {
                                 inside = (unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n;  // core.rs:129-134
@@ -362,11 +381,7 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                                     k_end = cell_start[cell + 1];
                                     break;
                                 }
-                                if (tmx < tmy) {
-                                    if (tmx < tmz) { ix += sx; tmx += tdx; } else { iz += sz; tmz += tdz; }
-                                } else {
-                                    if (tmy < tmz) { iy += sy; tmy += tdy; } else { iz += sz; tmz += tdz; }
-                                }
+                                RTW_DDA_ADVANCE();
                             }
                             if (!inside) {  // left the grid without a hit
                                 model_i = mm + 1;
@@ -374,32 +389,50 @@ __global__ __launch_bounds__(256, RTM_WAVE_OCC) void render_wave_kernel(RtmDevSc
                             }
                         }
                     }
-                    if (st == ST_TRAV && k < k_end) {  // one triangle test (model.rs:45-72)
-                        const uint32_t ti = tri_idx[k];
-                        ++k;
-                        if (STATS) cnt.v[C_TRI]++;
-                        const gptr<double> tp = tri_pos + (size_t)ti * 9;
-                        const V3 v0 = ld3(tp), v1 = ld3(tp + 3), v2 = ld3(tp + 6);
-                        const V3 e1 = v1 - v0, e2 = v2 - v0;
-                        const V3 p = cross(d, e2);
-                        const double det = dot(e1, p);
-                        if (!(fabs(det) < kF64Eps)) {
+                    if (st == ST_TRAV && k < k_end) {
+                        // Up to two consecutive list entries per step, evaluated branch-free (model.rs:45-72): the
+                        // reference's early returns become one predicate built from the same comparisons (so NaNs
+                        // take the same side), which removes four exec-mask regions per test and gives the
+                        // scheduler two independent f64 chains.  Entry k is applied before k+1 (core.rs:140-142).
+                        const bool two = k + 1u < k_end;
+                        const uint32_t ti0 = tri_idx[k], ti1 = tri_idx[two ? k + 1u : k];
+                        if (STATS) cnt.v[C_TRI] += two ? 2u : 1u;
+                        k += two ? 2u : 1u;
+                        const gptr<double> ta = tri_pos + (size_t)ti0 * 9, tb = tri_pos + (size_t)ti1 * 9;
+                        const V3 a0 = ld3(ta), a1 = ld3(ta + 3), a2 = ld3(ta + 6);
+                        const V3 b0 = ld3(tb), b1 = ld3(tb + 3), b2 = ld3(tb + 6);
+                        double t0, t1;
+                        bool ok0, ok1;
+                        {
+                            const V3 p = cross(d, a2);
+                            const double det = dot(a1, p);
                             const double inv = 1.0 / det;
-                            const V3 tv = o - v0;
+                            const V3 tv = o - a0;
                             const double u = dot(tv, p) * inv;
-                            if (!(u < 0.0 || u > 1.0)) {
-                                const V3 q = cross(tv, e1);
-                                const double v = dot(d, q) * inv;
-                                if (!(v < 0.0 || u + v > 1.0)) {
-                                    const double t = dot(e2, q) * inv;
-                                    if (!(t < 0.0) && (!have || t < m_t)) {  // core.rs:140-142
-                                        have = true;
-                                        m_t = t;
-                                        m_tri = ti;
-                                    }
-                                }
-                            }
+                            const V3 q = cross(tv, a1);
+                            const double v = dot(d, q) * inv;
+                            t0 = dot(a2, q) * inv;
+                            ok0 = !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(t0 < 0.0);
                         }
+                        {
+                            const V3 p = cross(d, b2);
+                            const double det = dot(b1, p);
+                            const double inv = 1.0 / det;
+                            const V3 tv = o - b0;
+                            const double u = dot(tv, p) * inv;
+                            const V3 q = cross(tv, b1);
+                            const double v = dot(d, q) * inv;
+                            t1 = dot(b2, q) * inv;
+                            ok1 = two && !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(t1 < 0.0);
+                        }
+                        const bool take0 = ok0 && (!have || t0 < m_t);
+                        m_t = take0 ? t0 : m_t;
+                        m_tri = take0 ? ti0 : m_tri;
+                        have = have || take0;
+                        const bool take1 = ok1 && (!have || t1 < m_t);
+                        m_t = take1 ? t1 : m_t;
+                        m_tri = take1 ? ti1 : m_tri;
+                        have = have || take1;
                     }
                 }
                 const unsigned long long still = __ballot(st == ST_TRAV && model_i == mm);

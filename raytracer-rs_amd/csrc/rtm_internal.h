@@ -22,7 +22,7 @@ struct RtmDevModel {
     uint32_t mat, obj;
     const uint32_t* cell_start;  // n^3 + 1, exclusive prefix (from the inclusive offset_array)
     const uint32_t* tri_idx;
-    const double* tri_pos;       // n_tris x 9: v0 xyz, v1 xyz, v2 xyz
+    const double* tri_pos;       // n_tris x 9: v0 xyz, (v1-v0) xyz, (v2-v0) xyz  -- edges of model.rs:46-47 / :20-21
     const double* tri_nrm;       // n_tris x 9
     const uint32_t* occupancy;   // n^3 bits: cell non-empty
 };
