@@ -189,7 +189,7 @@ def main():
                        "rays_shadow": cnt["rays_shadow"], "samples_per_s": W * H * args.spp * args.steps / dt,
                        "parallelism": f"row-interleave x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "render_kernel<false>", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "scene <= 1.8 MB is L2-resident: the binding limit is FP64 VALU issue + divergence, see valu"},
             "valu": {"achieved_tflops": flops / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
