@@ -122,20 +122,16 @@ def main():
     stream = torch.cuda.current_stream()
     local = torch.empty(rows, W, 3, dtype=torch.float64, device="cuda")
     scene.device_handle()  # scene resident in HBM before the timed region
-    equal_rows = H % world == 0
-    if world > 1:
-        gathered = torch.empty(world * rows if equal_rows else H + world, W, 3, dtype=torch.float64, device="cuda") if rank == 0 else None
-        frame = torch.empty(H, W, 3, dtype=torch.float64, device="cuda") if rank == 0 else None
-        if not equal_rows:
-            sys.exit("bench.py: height must be divisible by the number of GPUs")
+    if world > 1 and H % world != 0:
+        sys.exit("bench.py: height must be divisible by the number of GPUs")
+    from raytracer_rs_amd.distributed import gather_frame
+    scratch = {}
 
     def step():
         scene.render_device(p_local, local.data_ptr(), stream=stream.cuda_stream)
         if world > 1:
             # one gather of the compact row blocks to rank 0 over xGMI (RCCL), then de-interleave
-            dist.gather(local, list(gathered.view(world, rows, W, 3).unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                rtm.deinterleave_device(gathered.data_ptr(), W, H, world, frame.data_ptr(), stream=stream.cuda_stream)
+            gather_frame(local, H, W, rank, world, deinterleave_device=rtm.deinterleave_device, scratch=scratch)
 
     def barrier():
         if world > 1:
