@@ -415,8 +415,9 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         (void)hipFree(d_cnt);
         if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
         if (std::getenv("RTM_DIAG") && h[9])
-            std::fprintf(stderr, "[rtm diag] S rounds %llu (avg %.1f lanes)  T steps %llu (avg %.1f lanes)\n", h[9], (double)h[10] / (double)h[9], h[11],
-                         h[11] ? (double)h[12] / (double)h[11] : 0.0);
+            std::fprintf(stderr, "[rtm diag] S rounds %llu (avg %.1f lanes, %.0f cyc/round)  T steps %llu (avg %.1f lanes, %.0f cyc/step)  wave cycles: S %.1f%% T %.1f%% of %.3g\n",
+                         h[9], (double)h[10] / (double)h[9], (double)h[13] / (double)h[9], h[11], h[11] ? (double)h[12] / (double)h[11] : 0.0,
+                         h[11] ? (double)h[14] / (double)h[11] : 0.0, 100.0 * (double)h[13] / (double)h[15], 100.0 * (double)h[14] / (double)h[15], (double)h[15]);
         out_stats->rays_camera = h[0]; out_stats->rays_bounce = h[1]; out_stats->rays_shadow = h[2];
         out_stats->sphere_tests = h[3]; out_stats->plane_tests = h[4]; out_stats->bbox_tests = h[5];
         out_stats->cells_visited = h[6]; out_stats->tri_tests = h[7]; out_stats->model_hits = h[8];

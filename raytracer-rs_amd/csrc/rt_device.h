@@ -160,8 +160,8 @@ RTM_DEV bool model_intersect(const RtmDevModel& M, V3 o, V3 d, double& t_out, ui
     return true;
 }
 
-// model.rs:18-39 at hit_point = ray.at(t)  (core.rs:169-177)
-RTM_DEV V3 model_normal(const RtmDevModel& M, uint32_t ti, V3 point) {
+// model.rs:18-39 at hit_point = ray.at(t)  (core.rs:169-177); _raw stops before the final normalize
+RTM_DEV V3 model_normal_raw(const RtmDevModel& M, uint32_t ti, V3 point) {
     const gptr<double> tp = as_global(M.tri_pos) + (size_t)ti * 9;
     const gptr<double> np = as_global(M.tri_nrm) + (size_t)ti * 9;
     const V3 v0 = ld3(tp), s0 = ld3(tp + 3), s1 = ld3(tp + 6), s2 = point - v0;  // s0 = v1-v0, s1 = v2-v0 (model.rs:20-21)
@@ -170,8 +170,9 @@ RTM_DEV V3 model_normal(const RtmDevModel& M, uint32_t ti, V3 point) {
     const double v = (d11 * d20 - d01 * d21) / den;
     const double w = (d00 * d21 - d01 * d20) / den;
     const double u = 1.0 - v - w;
-    return normalize(ld3(np) * u + ld3(np + 3) * v + ld3(np + 6) * w);
+    return ld3(np) * u + ld3(np + 3) * v + ld3(np + 6) * w;
 }
+RTM_DEV V3 model_normal(const RtmDevModel& M, uint32_t ti, V3 point) { return normalize(model_normal_raw(M, ti, point)); }
 
 // ---- hit (core.rs:68-92).  Objects are visited per kind, not in file order: the reference's
 // "strictly smaller t, so the earliest object wins a tie" (core.rs:79) is kept by breaking ties on

@@ -34,6 +34,9 @@ using namespace rtd;
 #ifndef RTM_WAVE_OCC
 #define RTM_WAVE_OCC 4  // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef RTM_TRI_WIDE
+#define RTM_TRI_WIDE 4  // list entries tested per traversal step
+#endif
 constexpr int kBlock = 256;
 constexpr int kColdFields = 17;                       // doubles of S-only state per lane, see enum below
 constexpr int kColdBytes = kColdFields * kBlock * 8;  // 34,816 B per workgroup
@@ -128,6 +131,8 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
     } while (0)
 
     uint64_t dg_s_rounds = 0, dg_s_lanes = 0, dg_t_steps = 0, dg_t_lanes = 0;  // scheduler diagnostics (STATS build only)
+    uint64_t dg_s_cyc = 0, dg_t_cyc = 0, dg_t0 = 0;
+    const uint64_t dg_begin = STATS ? __builtin_amdgcn_s_memtime() : 0;
     for (;;) {
         // ---- hand out pixels to idle lanes
         for (;;) {
@@ -169,42 +174,56 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
         const uint32_t s_need = (A.s_threshold * live + 63u) >> 6;
         if (!traversing || (uint32_t)__popcll(waiting) >= s_need) {
             // =========================== S round ===========================
-            if (STATS) { dg_s_rounds++; dg_s_lanes += (uint64_t)__popcll(waiting); }
+            if (STATS) { dg_s_rounds++; dg_s_lanes += (uint64_t)__popcll(waiting); dg_t0 = __builtin_amdgcn_s_memtime(); }
             if (st == ST_CONSUME) {
-                bool gen = false, finish = false, end_sample = false, next_shadow = false;
-                if (phase == PH_PATH) {
-                    if (bounce == 0 && s == 0) { obj0 = found ? h_obj : kNoId; tri0 = found ? h_tri : kNoId; }
-                    if (!found) {
-                        stc3(F_COLOR, ldc3(F_COLOR) + mk(1, 1, 1) * ldc(F_ATT));  // main.rs:127
-                        end_sample = true;
-                    } else {
-                        const V3 P = ray_at(o, d, best);  // core.rs:89
-                        const uint32_t kind = h_kp >> 30, prim = h_kp & 0x3FFFFFFFu;
-                        V3 nn;
-                        if (kind == 0u) nn = normalize(ray_at(o, d, best) - ld3(S.spheres + (size_t)prim * 4));  // core.rs:195
-                        else if (kind == 1u) nn = ld3(S.planes + (size_t)prim * 4);                              // core.rs:209
-                        else nn = model_normal(S.models[prim], h_tri, P);                                        // core.rs:169-177
-                        if (dot(d, nn) > 0.001) nn = nn * -1.0;  // main.rs:68-73
-                        mat = h_mat;
-                        V3 bdir;
-                        if (S.materials[(size_t)mat * 4 + 3] != 0.0) {
-                            bdir = d - nn * 2.0 * dot(d, nn);  // vec3.rs:172-175 (metal)
-                        } else {
-                            uint32_t ra[4], rb[4];
-                            philox(A.seed, pixel, s, 1u + 2u * (uint32_t)bounce, ra);
-                            philox(A.seed, pixel, s, 2u + 2u * (uint32_t)bounce, rb);
-                            const V3 rnd = mk(u01(ra[0], ra[1]) * (1.0 - 0.0) + 0.0, u01(ra[2], ra[3]) * (1.0 - 0.0) + 0.0,
-                                              u01(rb[0], rb[1]) * (1.0 - 0.0) + 0.0);
-                            bdir = normalize(nn + rnd);  // main.rs:53
-                        }
-                        stc3(F_NRM, nn);
-                        stc3(F_BD, bdir);
-                        stc3(F_DIFF, mk(0, 0, 0));
-                        o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
-                        li = 0;
-                        if (S.n_lights == 0u) finish = true; else next_shadow = true;
-                    }
-                } else if (phase == PH_SHADOW) {  // main.rs:86-104 for light li; o == P
+                // "Decide, then do": lanes of a wave sit in different phases, so every expensive block below exists
+                // once and serves whichever lanes need it this round (one Philox pair, one normal normalisation, one
+                // direction normalisation), instead of once per phase.
+                // ---- 0. cheap per-lane decisions (integer state only)
+                const bool path = phase == PH_PATH, shadow = phase == PH_SHADOW;
+                const bool path_hit = path && found, path_miss = path && !found;
+                if (path && bounce == 0 && s == 0) { obj0 = found ? h_obj : kNoId; tri0 = found ? h_tri : kNoId; }
+                if (path_hit) mat = h_mat;
+                const bool metal = S.materials[(size_t)mat * 4 + 3] != 0.0;  // material of the surface being shaded
+                const bool plastic_hit = path_hit && !metal;
+                const bool finish = (path_hit && S.n_lights == 0u) || (shadow && li + 1u >= S.n_lights);
+                const bool next_shadow = (path_hit && S.n_lights != 0u) || (shadow && li + 1u < S.n_lights);
+                const bool end_sample = path_miss || (finish && bounce + 1 >= K);
+                const bool last_sample = end_sample && s + 1u >= A.spp;
+                const bool gen = phase == PH_START || (end_sample && !last_sample);
+                // ---- 1. random numbers: Vec3::random() of this bounce (vec3.rs:160-162) or the next sample's jitter
+                //         (main.rs:162-163); both are pure functions of (seed, pixel, sample, stream)
+                uint32_t ra[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+                if (plastic_hit || gen) {
+                    const uint32_t smp = gen ? (phase == PH_START ? s : s + 1u) : s;
+                    philox(A.seed, pixel, smp, gen ? 0u : 1u + 2u * (uint32_t)bounce, ra);
+                }
+                if (plastic_hit) philox(A.seed, pixel, s, 2u + 2u * (uint32_t)bounce, rb);
+                // ---- 2. surface point and shading normal of a path hit (core.rs:89,169-177,195,209; main.rs:68-73)
+                if (path_hit) {
+                    const V3 P = ray_at(o, d, best);
+                    const uint32_t kind = h_kp >> 30, prim = h_kp & 0x3FFFFFFFu;
+                    V3 raw;
+                    if (kind == 0u) raw = ray_at(o, d, best) - ld3(S.spheres + (size_t)prim * 4);
+                    else if (kind == 1u) raw = ld3(S.planes + (size_t)prim * 4);  // used as written, not normalised
+                    else raw = model_normal_raw(S.models[prim], h_tri, P);
+                    V3 nn = normalize(raw);
+                    if (kind == 1u) nn = raw;
+                    if (dot(d, nn) > 0.001) nn = nn * -1.0;
+                    // bounce direction (main.rs:50-55): metal reflects (not renormalised, vec3.rs:172-175); plastic is
+                    // normalize(n + random()), whose normalisation is done when the bounce ray is issued (step 6)
+                    const V3 rnd = mk(u01(ra[0], ra[1]) * (1.0 - 0.0) + 0.0, u01(ra[2], ra[3]) * (1.0 - 0.0) + 0.0,
+                                      u01(rb[0], rb[1]) * (1.0 - 0.0) + 0.0);
+                    const V3 refl = d - nn * 2.0 * dot(d, nn);
+                    const V3 diff = nn + rnd;
+                    stc3(F_NRM, nn);
+                    stc3(F_BD, metal ? refl : diff);
+                    stc3(F_DIFF, mk(0, 0, 0));
+                    o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
+                    li = 0;
+                }
+                // ---- 3. result of a shadow query (main.rs:86-104), light li; o == P
+                if (shadow) {
                     const double* L = S.lights + (size_t)li * 8;
                     const double dl2 = ldc(F_DL2);
                     bool occluded = false;
@@ -218,31 +237,26 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                         }
                     }
                     ++li;
-                    if (li >= S.n_lights) finish = true; else next_shadow = true;
-                } else {
-                    gen = true;
                 }
-                if (finish) {  // main.rs:107-125
+                // ---- 4. end of the light loop: add the surface's colour, attenuate (main.rs:107-125)
+                V3 newdir = mk(0, 0, 1);
+                bool need_norm = false;
+                if (path_miss) stc3(F_COLOR, ldc3(F_COLOR) + mk(1, 1, 1) * ldc(F_ATT));  // main.rs:127
+                if (finish) {
                     const double* mp = S.materials + (size_t)mat * 4;
-                    const bool metal = mp[3] != 0.0;
                     const double att = ldc(F_ATT);
                     stc3(F_COLOR, ldc3(F_COLOR) + ld3(mp) * att * (ldc3(F_DIFF) * (metal ? 0.2 : 0.9)));
-                    d = ldc3(F_BD);
                     stc(F_ATT, att * (metal ? 0.8 : 0.1));
+                    newdir = ldc3(F_BD);
+                    need_norm = !metal;
                     ++bounce;
                     phase = PH_PATH;
-                    if (bounce >= K) end_sample = true;
-                } else if (next_shadow) {  // main.rs:80-85
-                    const V3 lp = ld3(S.lights + (size_t)li * 8);
-                    d = normalize(lp - o);
-                    stc(F_DL2, sqdist(o, lp));
-                    phase = PH_SHADOW;
-                    if (STATS) cnt.v[C_SHADOW]++;
                 }
+                // ---- 5. end of a sample: pixel accumulation in sample order (main.rs:169)
                 if (end_sample) {
-                    const V3 px = ldc3(F_PX) + ldc3(F_COLOR) / n_spp;  // main.rs:169
+                    const V3 px = ldc3(F_PX) + ldc3(F_COLOR) / n_spp;
                     ++s;
-                    if (s >= A.spp) {
+                    if (last_sample) {
                         const size_t oi = (size_t)ly * A.W + x;
                         out_rgb[oi * 3] = px.x;
                         out_rgb[oi * 3 + 1] = px.y;
@@ -252,22 +266,37 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                         st = ST_FETCH;
                     } else {
                         stc3(F_PX, px);
-                        gen = true;
                     }
                 }
-                if (gen) {  // main.rs:160-168
+                // ---- 6. the next ray: shadow ray to light li (main.rs:80-85), bounce ray, or camera ray (main.rs:160-168)
+                if (next_shadow) {
+                    const V3 lp = ld3(S.lights + (size_t)li * 8);
+                    newdir = lp - o;
+                    need_norm = true;
+                    stc(F_DL2, sqdist(o, lp));
+                    phase = PH_SHADOW;
+                    if (STATS) cnt.v[C_SHADOW]++;
+                }
+                if (gen) {
                     double xo = 0.0, yo = 0.0;
                     if (!(A.flags & RTM_FLAG_ZERO_JITTER)) {
-                        uint32_t r[4];
-                        philox(A.seed, pixel, s, 0u, r);
-                        xo = u01(r[0], r[1]) * (0.5 - -0.5) + -0.5;
-                        yo = u01(r[2], r[3]) * (0.5 - -0.5) + -0.5;
+                        xo = u01(ra[0], ra[1]) * (0.5 - -0.5) + -0.5;
+                        yo = u01(ra[2], ra[3]) * (0.5 - -0.5) + -0.5;
                     }
-                    camera_ray(S, x, A.row_begin + ly * A.row_stride, A.W, A.H, xo, yo, o, d);
+                    const uint32_t yy = A.row_begin + ly * A.row_stride;
+                    const double u = ((double)x + xo - (double)A.W * 0.5) / (double)A.W;   // main.rs:165
+                    const double v = ((double)yy + yo - (double)A.H * 0.5) / (double)A.H;  // main.rs:166
+                    newdir = ld3(S.cam_fwd) * S.cam_zoom + ld3(S.cam_up) * v + ld3(S.cam_right) * u;  // camera.rs:47
+                    need_norm = true;
+                    o = ld3(S.cam_pos);
                     stc3(F_COLOR, mk(0, 0, 0));
                     stc(F_ATT, 1.0);
                     bounce = 0;
                     phase = PH_PATH;
+                }
+                {
+                    const V3 nd = normalize(newdir);  // vec3.rs:213-215: three divisions by the length
+                    d = need_norm ? nd : newdir;
                 }
                 if (st != ST_FETCH) {
                     // ---- new query: analytic primitives (core.rs:183-210)
@@ -335,9 +364,11 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                 }
             }
             if (st == ST_ENTER) st = ST_CONSUME;  // no model left: the query is complete
+            if (STATS) dg_s_cyc += __builtin_amdgcn_s_memtime() - dg_t0;
         } else {
             // =========================== T loop ===========================
             // lanes traversing the same model as the first traversing lane step together (mm is wave-uniform)
+            if (STATS) dg_t0 = __builtin_amdgcn_s_memtime();
             const int first = __ffsll((long long)traversing) - 1;
             const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)model_i, first);
             uint32_t occ_base = 0;  // LDS word offset of this model's bitmap, or 0xFFFFFFFF when it stayed in HBM
@@ -390,49 +421,41 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                         }
                     }
                     if (st == ST_TRAV && k < k_end) {
-                        // Up to two consecutive list entries per step, evaluated branch-free (model.rs:45-72): the
-                        // reference's early returns become one predicate built from the same comparisons (so NaNs
-                        // take the same side), which removes four exec-mask regions per test and gives the
-                        // scheduler two independent f64 chains.  Entry k is applied before k+1 (core.rs:140-142).
-                        const bool two = k + 1u < k_end;
-                        const uint32_t ti0 = tri_idx[k], ti1 = tri_idx[two ? k + 1u : k];
-                        if (STATS) cnt.v[C_TRI] += two ? 2u : 1u;
-                        k += two ? 2u : 1u;
-                        const gptr<double> ta = tri_pos + (size_t)ti0 * 9, tb = tri_pos + (size_t)ti1 * 9;
-                        const V3 a0 = ld3(ta), a1 = ld3(ta + 3), a2 = ld3(ta + 6);
-                        const V3 b0 = ld3(tb), b1 = ld3(tb + 3), b2 = ld3(tb + 6);
-                        double t0, t1;
-                        bool ok0, ok1;
-                        {
-                            const V3 p = cross(d, a2);
-                            const double det = dot(a1, p);
+                        // Up to RTM_TRI_WIDE consecutive list entries per step, evaluated branch-free (model.rs:45-72):
+                        // the reference's early returns become one predicate built from the same comparisons (so
+                        // NaNs take the same side), which removes four exec-mask regions per test and gives the
+                        // scheduler independent f64 chains.  Entries are applied in list order (core.rs:140-142).
+                        const uint32_t left = k_end - k;
+                        const uint32_t cntw = left < (uint32_t)RTM_TRI_WIDE ? left : (uint32_t)RTM_TRI_WIDE;
+                        uint32_t ti[RTM_TRI_WIDE];
+                        double tt[RTM_TRI_WIDE];
+                        bool ok[RTM_TRI_WIDE];
+#pragma unroll
+                        for (int j = 0; j < RTM_TRI_WIDE; ++j) ti[j] = tri_idx[k + ((uint32_t)j < cntw ? (uint32_t)j : 0u)];
+#pragma unroll
+                        for (int j = 0; j < RTM_TRI_WIDE; ++j) {
+                            const gptr<double> tp = tri_pos + (size_t)ti[j] * 9;
+                            const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
+                            const V3 p = cross(d, e2);
+                            const double det = dot(e1, p);
                             const double inv = 1.0 / det;
-                            const V3 tv = o - a0;
+                            const V3 tv = o - v0;
                             const double u = dot(tv, p) * inv;
-                            const V3 q = cross(tv, a1);
+                            const V3 q = cross(tv, e1);
                             const double v = dot(d, q) * inv;
-                            t0 = dot(a2, q) * inv;
-                            ok0 = !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(t0 < 0.0);
+                            tt[j] = dot(e2, q) * inv;
+                            ok[j] = (uint32_t)j < cntw && !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) &&
+                                    !(tt[j] < 0.0);
                         }
-                        {
-                            const V3 p = cross(d, b2);
-                            const double det = dot(b1, p);
-                            const double inv = 1.0 / det;
-                            const V3 tv = o - b0;
-                            const double u = dot(tv, p) * inv;
-                            const V3 q = cross(tv, b1);
-                            const double v = dot(d, q) * inv;
-                            t1 = dot(b2, q) * inv;
-                            ok1 = two && !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(t1 < 0.0);
+#pragma unroll
+                        for (int j = 0; j < RTM_TRI_WIDE; ++j) {
+                            const bool take = ok[j] && (!have || tt[j] < m_t);
+                            m_t = take ? tt[j] : m_t;
+                            m_tri = take ? ti[j] : m_tri;
+                            have = have || take;
                         }
-                        const bool take0 = ok0 && (!have || t0 < m_t);
-                        m_t = take0 ? t0 : m_t;
-                        m_tri = take0 ? ti0 : m_tri;
-                        have = have || take0;
-                        const bool take1 = ok1 && (!have || t1 < m_t);
-                        m_t = take1 ? t1 : m_t;
-                        m_tri = take1 ? ti1 : m_tri;
-                        have = have || take1;
+                        if (STATS) cnt.v[C_TRI] += cntw;
+                        k += cntw;
                     }
                 }
                 const unsigned long long still = __ballot(st == ST_TRAV && model_i == mm);
@@ -440,6 +463,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                 const unsigned long long w2 = __ballot(st == ST_CONSUME || st == ST_ENTER);
                 if ((uint32_t)__popcll(still) * 64u < A.t_min_lanes * live && (uint32_t)__popcll(w2) >= s_need) break;
             }
+            if (STATS) dg_t_cyc += __builtin_amdgcn_s_memtime() - dg_t0;
         }
     }
     if (STATS) {
@@ -458,6 +482,9 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
             atomicAdd(out_cnt + 10, (unsigned long long)dg_s_lanes);
             atomicAdd(out_cnt + 11, (unsigned long long)dg_t_steps);
             atomicAdd(out_cnt + 12, (unsigned long long)dg_t_lanes);
+            atomicAdd(out_cnt + 13, (unsigned long long)dg_s_cyc);
+            atomicAdd(out_cnt + 14, (unsigned long long)dg_t_cyc);
+            atomicAdd(out_cnt + 15, (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_begin));
         }
     }
 }
