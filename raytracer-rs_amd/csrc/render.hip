@@ -32,7 +32,7 @@ int rtm_internal_fail(int code, const std::string& msg) {
 static int g_device = -1;
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
-static uint32_t g_s_threshold = 32, g_t_min_lanes = 16;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
+static uint32_t g_s_threshold = 32, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------
 // kernels

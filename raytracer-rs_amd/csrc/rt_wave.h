@@ -434,6 +434,11 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                         for (int j = 0; j < RTM_TRI_WIDE; ++j) ti[j] = tri_idx[k + ((uint32_t)j < cntw ? (uint32_t)j : 0u)];
 #pragma unroll
                         for (int j = 0; j < RTM_TRI_WIDE; ++j) {
+                            tt[j] = 0.0;
+                            ok[j] = false;
+                            // slots beyond the second are evaluated only when some lane of the wave has that many
+                            // entries left in its cell (wave-uniform branch: lists along a ray are mostly short)
+                            if (j >= 2 && !__ballot((uint32_t)j < cntw)) continue;
                             const gptr<double> tp = tri_pos + (size_t)ti[j] * 9;
                             const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
                             const V3 p = cross(d, e2);
