@@ -47,9 +47,12 @@ def soup_scene(rtm, n_tris: int, seed: int):
     """BASELINE config 5's synthetic soup: N triangles, centres U([-2,2]^3)+(0,0,7), edge vectors U([-s,s]^3)
     with s = 0.02, geometric normals, numpy Philox(seed); two planes and two lights as in the bunny scene."""
     import numpy as np
-    txt = ("size 1200 1200\n\ncamera from (4.0, -8, 0) to (0, 0, 7)\n\nplane (0, 0, 1.0) 10 white\n"
-           "plane (0, 1.0, 0) 2 metal:white\nlight (1, 0, 2) green\nlight (-1, 0, 2) blue")
-    s = rtm.Scene(text=txt, base_dir=ASSETS)
+    txt = ("size 3840 3840\n\ncamera from (4.0, -8, 0) to (0, 0, 7)\n\nplane (0, 0, 1.0) 10 white\n"
+           "plane (0, 1.0, 0) 2 metal:white\n"
+           'model "./models/teapot.obj" white > scale 0.4 > translate (2.5, 1.2, 6)\n'
+           "light (1, 0, 2) green\nlight (-1, 0, 2) blue")
+    # teapot.obj has no `vn` lines: the reference loader would refuse it; geometric normals are synthesised (stated)
+    s = rtm.Scene(text=txt, base_dir=ASSETS, synth_normals=True)
     rng = np.random.Generator(np.random.Philox(seed))
     c = rng.uniform(-2, 2, (n_tris, 1, 3)) + np.array([0.0, 0.0, 7.0])
     pos = (c + rng.uniform(-0.02, 0.02, (n_tris, 3, 3))).astype(np.float32)

@@ -88,7 +88,11 @@ class OracleScene:
             lib().orc_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     def _refresh(self):
         v = [C.c_uint32() for _ in range(5)]
