@@ -32,7 +32,8 @@ int rtm_internal_fail(int code, const std::string& msg) {
 static int g_device = -1;
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
-static uint32_t g_s_threshold = 32, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
+static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
+static uint32_t g_s_threshold = 24, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -261,6 +262,7 @@ int rtm_init(int device) {
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_TEST_FRAC")) g_t_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     return RTM_OK;
 }
@@ -379,7 +381,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     const bool v1 = (p->flags & RTM_FLAG_KERNEL_V1) != 0;
     RenderArgs A{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags};
     rtw::RenderArgsW AW{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags,
-                        g_s_threshold, g_t_min_lanes, (p->width + 7) / 8, ((p->width + 7) / 8) * ((n_rows + 7) / 8), 0u, g_work_counter};
+                        g_s_threshold, g_t_test_frac, g_t_min_lanes, (p->width + 7) / 8, ((p->width + 7) / 8) * ((n_rows + 7) / 8), 0u, g_work_counter};
     {   // occupancy bitmaps that fit the LDS budget, models in order (same rule as the kernel's staging loop)
         uint32_t words = 0;
         for (uint32_t w : sd->occ_words) {
@@ -406,10 +408,10 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     };
     if (out_stats) {
         unsigned long long* d_cnt = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_cnt, 16 * sizeof(unsigned long long)));
-        hipError_t e = hipMemsetAsync(d_cnt, 0, 16 * sizeof(unsigned long long), stream);
+        HIP_TRY(hipMalloc((void**)&d_cnt, 24 * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_cnt, 0, 24 * sizeof(unsigned long long), stream);
         if (e == hipSuccess) e = launch(true, d_cnt);
-        unsigned long long h[16] = {0};
+        unsigned long long h[24] = {0};
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         (void)hipFree(d_cnt);
@@ -418,6 +420,9 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
             std::fprintf(stderr, "[rtm diag] S rounds %llu (avg %.1f lanes, %.0f cyc/round)  T steps %llu (avg %.1f lanes, %.0f cyc/step)  wave cycles: S %.1f%% T %.1f%% of %.3g\n",
                          h[9], (double)h[10] / (double)h[9], (double)h[13] / (double)h[9], h[11], h[11] ? (double)h[12] / (double)h[11] : 0.0,
                          h[11] ? (double)h[14] / (double)h[11] : 0.0, 100.0 * (double)h[13] / (double)h[15], 100.0 * (double)h[14] / (double)h[15], (double)h[15]);
+        if (std::getenv("RTM_DIAG") && h[9])
+            std::fprintf(stderr, "[rtm diag] walks %llu wave-steps, %llu wave-iters (avg %.1f lanes); test slots %llu (avg %.1f lanes); bbox %llu cells %llu tri %llu mhit %llu\n",
+                         h[20], h[16], h[16] ? (double)h[17] / (double)h[16] : 0.0, h[18], h[18] ? (double)h[19] / (double)h[18] : 0.0, h[5], h[6], h[7], h[8]);
         out_stats->rays_camera = h[0]; out_stats->rays_bounce = h[1]; out_stats->rays_shadow = h[2];
         out_stats->sphere_tests = h[3]; out_stats->plane_tests = h[4]; out_stats->bbox_tests = h[5];
         out_stats->cells_visited = h[6]; out_stats->tri_tests = h[7]; out_stats->model_hits = h[8];

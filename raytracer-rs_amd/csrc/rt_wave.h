@@ -34,6 +34,9 @@ using namespace rtd;
 #ifndef RTM_WAVE_OCC
 #define RTM_WAVE_OCC 4  // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef RTM_WALK_UNROLL
+#define RTM_WALK_UNROLL 2  // DDA steps per walk iteration of the traversal loop
+#endif
 #ifndef RTM_TRI_WIDE
 #define RTM_TRI_WIDE 4  // list entries tested per traversal step
 #endif
@@ -51,6 +54,7 @@ struct RenderArgsW {
     uint64_t seed;
     uint32_t row_begin, row_stride, n_rows, flags;
     uint32_t s_threshold;  // per 64 live lanes: run an S round when at least this many wait (or nobody traverses)
+    uint32_t t_test_frac;  // per 64 traversing lanes: run a test step when at least this many have an open list, else a walk step
     uint32_t t_min_lanes;  // per 64 live lanes: leave the T loop below this many traversing lanes (if S is due)
     uint32_t tiles_x, n_tiles;  // 8x8 pixel tiles over width x n_rows; pixel ids are tile-major
     uint32_t occ_words;         // bitmap words staged in LDS (models in order, as many as fit)
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
     uint32_t k = 0, k_end = 0, m_tri = 0;
     double m_t = 0.0;
-    bool have = false, fresh = false;
+    bool have = false, fresh = false, open = false;  // open: the current cell's list [k, k_end) is not exhausted
 
     auto consider = [&](double t, uint32_t obj, uint32_t mt, uint32_t kp, uint32_t tri) {
         if (t <= kEps) return;                                  // core.rs:75-77
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
 
     uint64_t dg_s_rounds = 0, dg_s_lanes = 0, dg_t_steps = 0, dg_t_lanes = 0;  // scheduler diagnostics (STATS build only)
     uint64_t dg_s_cyc = 0, dg_t_cyc = 0, dg_t0 = 0;
+    uint64_t dg_walk_iters = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_walk_steps = 0;
     const uint64_t dg_begin = STATS ? __builtin_amdgcn_s_memtime() : 0;
     for (;;) {
         // ---- hand out pixels to idle lanes
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                         tdx = ((double)sx * M.cell[0]) / d.x;
                         tdy = ((double)sy * M.cell[1]) / d.y;
                         tdz = ((double)sz * M.cell[2]) / d.z;
-                        have = false; fresh = true; k = 0; k_end = 0;
+                        have = false; fresh = true; open = false;
                         st = ST_TRAV;
                     }
                 }
@@ -384,43 +389,51 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
             const gptr<double> tri_pos = as_global(M.tri_pos);
             const gptr<uint32_t> occ_glb = as_global(M.occupancy);
             const bool occ_in_lds = occ_base != 0xFFFFFFFFu;
+            // a ray leaving the last model has completed its query: it needs no further model-enter pass
+            const uint32_t after_model = mm + 1u < S.n_models ? ST_ENTER : ST_CONSUME;
             for (;;) {
-                const bool mine = st == ST_TRAV && model_i == mm;
-                if (STATS) { dg_t_steps++; dg_t_lanes += (uint64_t)__popcll(__ballot(mine)); }
-                if (mine) {
-                    if (k >= k_end) {  // current cell exhausted (or first cell)
-                        if (have) {    // core.rs:147-149: first cell with any accepted hit ends the walk
-                            if (STATS) cnt.v[C_MHIT]++;
-                            consider(m_t, M.obj, M.mat, (2u << 30) | mm, m_tri);
-                            model_i = mm + 1;
-                            st = ST_ENTER;
-                        } else {
-                            if (!fresh) RTW_DDA_ADVANCE();
+                // A traversing lane is either WALKING (looking for the next non-empty cell; one DDA step and one
+                // bitmap probe per iteration) or TESTING (its cell's list is open).  The two activities have very
+                // different lengths per ray -- a few lanes cross dozens of empty cells while the others have lists to
+                // scan -- so each loop iteration runs ONE of them, whichever has the lanes, instead of making every
+                // lane wait for the longest walk of the wave.
+                bool mine = st == ST_TRAV && model_i == mm;
+                if (mine && !open && have) {  // core.rs:147-149: first cell with any accepted hit ends the walk
+                    if (STATS) cnt.v[C_MHIT]++;
+                    consider(m_t, M.obj, M.mat, (2u << 30) | mm, m_tri);
+                    model_i = mm + 1;
+                    st = after_model;
+                    mine = false;
+                }
+                const uint32_t nW = (uint32_t)__popcll(__ballot(mine && !open));
+                const uint32_t nT = (uint32_t)__popcll(__ballot(mine && open));
+                if (nT == 0u || (nW != 0u && nT * 64u < A.t_test_frac * (nW + nT))) {
+                    if (STATS) { dg_walk_iters++; dg_walk_lanes += nW; }
+#pragma unroll
+                    for (int u = 0; u < RTM_WALK_UNROLL; ++u) {
+                        if (st == ST_TRAV && model_i == mm && !open) {
+                            if (!fresh) RTW_DDA_ADVANCE();  // core.rs:151-167
                             fresh = false;
-                            bool inside;
-                            // skip empty cells through the occupancy bitmap: the same DDA walk, no list to scan
-                            for (;;) {
-                                inside = (unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n;  // core.rs:129-134
-                                if (!inside) break;
+                            if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {  // core.rs:129-134
                                 if (STATS) cnt.v[C_CELLS]++;
                                 const uint32_t cell = ((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix;
                                 uint32_t word;
                                 if (occ_in_lds) word = occ_lds[occ_base + (cell >> 5)];
                                 else word = occ_glb[cell >> 5];
-                                if ((word >> (cell & 31u)) & 1u) {
+                                if ((word >> (cell & 31u)) & 1u) {  // non-empty: the list is [k, k_end), k < k_end
                                     k = cell_start[cell];
                                     k_end = cell_start[cell + 1];
-                                    break;
+                                    open = true;
                                 }
-                                RTW_DDA_ADVANCE();
-                            }
-                            if (!inside) {  // left the grid without a hit
+                            } else {  // left the grid without a hit
                                 model_i = mm + 1;
-                                st = ST_ENTER;
+                                st = after_model;
                             }
                         }
                     }
-                    if (st == ST_TRAV && k < k_end) {
+                } else {
+                    if (STATS) { dg_t_steps++; dg_t_lanes += nT; }
+                    if (mine && open) {
                         // Up to RTM_TRI_WIDE consecutive list entries per step, evaluated branch-free (model.rs:45-72):
                         // the reference's early returns become one predicate built from the same comparisons (so
                         // NaNs take the same side), which removes four exec-mask regions per test and gives the
@@ -438,7 +451,9 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                             ok[j] = false;
                             // slots beyond the second are evaluated only when some lane of the wave has that many
                             // entries left in its cell (wave-uniform branch: lists along a ray are mostly short)
-                            if (j >= 2 && !__ballot((uint32_t)j < cntw)) continue;
+                            const unsigned long long wants = __ballot((uint32_t)j < cntw);
+                            if (j >= 2 && !wants) continue;
+                            if (STATS) { dg_slots++; dg_slot_lanes += (uint64_t)__popcll(wants); }
                             const gptr<double> tp = tri_pos + (size_t)ti[j] * 9;
                             const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
                             const V3 p = cross(d, e2);
@@ -461,6 +476,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                         }
                         if (STATS) cnt.v[C_TRI] += cntw;
                         k += cntw;
+                        open = k < k_end;
                     }
                 }
                 const unsigned long long still = __ballot(st == ST_TRAV && model_i == mm);
@@ -490,6 +506,11 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
             atomicAdd(out_cnt + 13, (unsigned long long)dg_s_cyc);
             atomicAdd(out_cnt + 14, (unsigned long long)dg_t_cyc);
             atomicAdd(out_cnt + 15, (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_begin));
+        }
+        if (lane == 0) {  // wave-uniform traversal diagnostics
+            uint64_t dv[5] = {dg_walk_iters, dg_walk_lanes, dg_slots, dg_slot_lanes, dg_walk_steps};
+            for (int i = 0; i < 5; ++i)
+                if (dv[i]) atomicAdd(out_cnt + 16 + i, (unsigned long long)dv[i]);
         }
     }
 }
