@@ -11,7 +11,7 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_device.h"
-#include "rt_wave.h"
+#include "rt_multi.h"
 
 #pragma clang fp contract(off)
 
@@ -33,6 +33,7 @@ static int g_device = -1;
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
+static int g_kernel = 1;              // 0: rt_wave.h (one query per lane), 1: rt_multi.h (three); env RTM_KERNEL=wave|multi
 static uint32_t g_s_threshold = 24, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------
@@ -261,6 +262,7 @@ int rtm_init(int device) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : 1;
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_TEST_FRAC")) g_t_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
@@ -390,9 +392,11 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         }
         AW.occ_words = words;
     }
-    const size_t wave_lds = (size_t)rtw::kColdBytes + (size_t)AW.occ_words * 4;
+    const bool multi = g_kernel == 1;
+    const size_t wave_lds = (size_t)(multi ? rtq::kColdBytes : rtw::kColdBytes) + (size_t)AW.occ_words * 4;
     // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; each wave claims 8x8 tiles
-    static const uint32_t wgs_per_cu = std::getenv("RTM_WGS_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("RTM_WGS_PER_CU"))) : 4u;
+    static const uint32_t wgs_env = std::getenv("RTM_WGS_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("RTM_WGS_PER_CU"))) : 0u;
+    const uint32_t wgs_per_cu = wgs_env ? wgs_env : (multi ? (uint32_t)RTM_MULTI_OCC : (uint32_t)RTM_WAVE_OCC);
     const uint32_t wave_wgs = std::min<uint32_t>((AW.n_tiles + 3) / 4, (uint32_t)g_num_cus * wgs_per_cu);
     auto launch = [&](bool stats, unsigned long long* d_cnt) {
         if (v1) {
@@ -401,17 +405,22 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         } else {
             hipError_t me = hipMemsetAsync(g_work_counter, 0, 256, stream);  // claimed tiles start at 0 every frame
             if (me != hipSuccess) return me;
-            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            if (multi) {
+                if (stats) hipLaunchKernelGGL(rtq::render_multi_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+                else hipLaunchKernelGGL(rtq::render_multi_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            } else {
+                if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+                else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            }
         }
         return hipGetLastError();
     };
     if (out_stats) {
         unsigned long long* d_cnt = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_cnt, 24 * sizeof(unsigned long long)));
-        hipError_t e = hipMemsetAsync(d_cnt, 0, 24 * sizeof(unsigned long long), stream);
+        HIP_TRY(hipMalloc((void**)&d_cnt, 32 * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_cnt, 0, 32 * sizeof(unsigned long long), stream);
         if (e == hipSuccess) e = launch(true, d_cnt);
-        unsigned long long h[24] = {0};
+        unsigned long long h[32] = {0};
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         (void)hipFree(d_cnt);
@@ -423,6 +432,10 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         if (std::getenv("RTM_DIAG") && h[9])
             std::fprintf(stderr, "[rtm diag] walks %llu wave-steps, %llu wave-iters (avg %.1f lanes); test slots %llu (avg %.1f lanes); bbox %llu cells %llu tri %llu mhit %llu\n",
                          h[20], h[16], h[16] ? (double)h[17] / (double)h[16] : 0.0, h[18], h[18] ? (double)h[19] / (double)h[18] : 0.0, h[5], h[6], h[7], h[8]);
+        if (std::getenv("RTM_DIAG") && h[9] && h[24])
+            std::fprintf(stderr, "[rtm diag] S sub-blocks (cyc/round): decide+rng %.0f  normal %.0f  shadow+finish+sample %.0f  next-ray %.0f  analytic %.0f  enter %.0f\n",
+                         (double)h[24] / (double)h[9], (double)h[25] / (double)h[9], (double)h[26] / (double)h[9], (double)h[27] / (double)h[9],
+                         (double)h[28] / (double)h[9], (double)h[29] / (double)h[9]);
         out_stats->rays_camera = h[0]; out_stats->rays_bounce = h[1]; out_stats->rays_shadow = h[2];
         out_stats->sphere_tests = h[3]; out_stats->plane_tests = h[4]; out_stats->bbox_tests = h[5];
         out_stats->cells_visited = h[6]; out_stats->tri_tests = h[7]; out_stats->model_hits = h[8];

@@ -136,6 +136,8 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
 
     uint64_t dg_s_rounds = 0, dg_s_lanes = 0, dg_t_steps = 0, dg_t_lanes = 0;  // scheduler diagnostics (STATS build only)
     uint64_t dg_s_cyc = 0, dg_t_cyc = 0, dg_t0 = 0;
+    uint64_t dg_sb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_tm = 0;  // S-round sub-block cycles
+#define RTW_MARK(i) do { if (STATS) { const uint64_t n_ = __builtin_amdgcn_s_memtime(); dg_sb[i] += n_ - dg_tm; dg_tm = n_; } } while (0)
     uint64_t dg_walk_iters = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_walk_steps = 0;
     const uint64_t dg_begin = STATS ? __builtin_amdgcn_s_memtime() : 0;
     for (;;) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
         const uint32_t s_need = (A.s_threshold * live + 63u) >> 6;
         if (!traversing || (uint32_t)__popcll(waiting) >= s_need) {
             // =========================== S round ===========================
-            if (STATS) { dg_s_rounds++; dg_s_lanes += (uint64_t)__popcll(waiting); dg_t0 = __builtin_amdgcn_s_memtime(); }
+            if (STATS) { dg_s_rounds++; dg_s_lanes += (uint64_t)__popcll(waiting); dg_t0 = __builtin_amdgcn_s_memtime(); dg_tm = dg_t0; }
             if (st == ST_CONSUME) {
                 // "Decide, then do": lanes of a wave sit in different phases, so every expensive block below exists
                 // once and serves whichever lanes need it this round (one Philox pair, one normal normalisation, one
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                     philox(A.seed, pixel, smp, gen ? 0u : 1u + 2u * (uint32_t)bounce, ra);
                 }
                 if (plastic_hit) philox(A.seed, pixel, s, 2u + 2u * (uint32_t)bounce, rb);
+                RTW_MARK(0);
                 // ---- 2. surface point and shading normal of a path hit (core.rs:89,169-177,195,209; main.rs:68-73)
                 if (path_hit) {
                     const V3 P = ray_at(o, d, best);
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                     o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
                     li = 0;
                 }
+                RTW_MARK(1);
                 // ---- 3. result of a shadow query (main.rs:86-104), light li; o == P
                 if (shadow) {
                     const double* L = S.lights + (size_t)li * 8;
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                         stc3(F_PX, px);
                     }
                 }
+                RTW_MARK(2);
                 // ---- 6. the next ray: shadow ray to light li (main.rs:80-85), bounce ray, or camera ray (main.rs:160-168)
                 if (next_shadow) {
                     const V3 lp = ld3(S.lights + (size_t)li * 8);
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                     const V3 nd = normalize(newdir);  // vec3.rs:213-215: three divisions by the length
                     d = need_norm ? nd : newdir;
                 }
+                RTW_MARK(3);
                 if (st != ST_FETCH) {
                     // ---- new query: analytic primitives (core.rs:183-210)
                     if (STATS && phase == PH_PATH) cnt.v[bounce == 0 ? C_CAM : C_BOUNCE]++;
@@ -336,6 +342,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                     st = ST_ENTER;
                 }
             }
+            RTW_MARK(4);
             // ---- enter the next model whose box the ray meets (box3D.rs:64-93, core.rs:95-125); m is wave-uniform
             for (uint32_t m = 0; m < S.n_models; ++m) {
                 const RtmDevModel& M = S.models[m];
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                 }
             }
             if (st == ST_ENTER) st = ST_CONSUME;  // no model left: the query is complete
+            RTW_MARK(5);
             if (STATS) dg_s_cyc += __builtin_amdgcn_s_memtime() - dg_t0;
         } else {
             // =========================== T loop ===========================
@@ -511,6 +519,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
             uint64_t dv[5] = {dg_walk_iters, dg_walk_lanes, dg_slots, dg_slot_lanes, dg_walk_steps};
             for (int i = 0; i < 5; ++i)
                 if (dv[i]) atomicAdd(out_cnt + 16 + i, (unsigned long long)dv[i]);
+            for (int i = 0; i < 6; ++i) atomicAdd(out_cnt + 24 + i, (unsigned long long)dg_sb[i]);
         }
     }
 }
