@@ -12,6 +12,7 @@
 #include "../../include/rt_mi355x.h"
 #include "rt_device.h"
 #include "rt_multi.h"
+#include "rt_front.h"
 
 #pragma clang fp contract(off)
 
@@ -33,7 +34,14 @@ static int g_device = -1;
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
-static int g_kernel = 1;              // 0: rt_wave.h (one query per lane), 1: rt_multi.h (three); env RTM_KERNEL=wave|multi
+static int g_kernel = 0;              // 0: rt_wave.h, 1: rt_multi.h, 2: rt_front.h; env RTM_KERNEL=wave|multi|front
+static uint32_t g_front_refill = 16, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
+struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
+    char* base = nullptr;
+    size_t bytes = 0;
+};
+static FrontWorkspace g_front_ws;
+static size_t g_front_max_paths = 32u << 20;  // paths per band (668 B of workspace each); env RTM_FRONT_MAX_PATHS
 static uint32_t g_s_threshold = 24, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------
@@ -166,6 +174,7 @@ struct rtm_scene_dev {
     RtmDevScene view;
     std::vector<void*> allocs;
     std::vector<uint32_t> occ_words;  // per model: words of its cell-occupancy bitmap
+    uint32_t max_n = 0;               // largest cells_per_side
     int device;
 };
 
@@ -262,7 +271,11 @@ int rtm_init(int device) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : 1;
+    if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : (std::string(e) == "multi" ? 1 : 2);
+    if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
+    if (const char* e = std::getenv("RTM_FRONT_CULL")) g_front_cull = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(4096ll, std::atoll(e));
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_TEST_FRAC")) g_t_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
@@ -272,6 +285,9 @@ int rtm_init(int device) {
 int rtm_shutdown(void) {
     if (g_work_counter) (void)hipFree(g_work_counter);
     g_work_counter = nullptr;
+    if (g_front_ws.base) (void)hipFree(g_front_ws.base);
+    g_front_ws.base = nullptr;
+    g_front_ws.bytes = 0;
     g_device = -1;
     return RTM_OK;
 }
@@ -339,6 +355,7 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             D.hc[c] = M.bbox_half[c] / n;
             D.hc2[c] = D.hc[c] * 2.0;
         }
+        sd->max_n = std::max(sd->max_n, M.cells_per_side);
         D.n = M.cells_per_side; D.n_tris = M.n_tris; D.mat = M.mat_idx; D.obj = M.obj_idx;
         const size_t n3 = (size_t)M.cells_per_side * M.cells_per_side * M.cells_per_side;
         std::vector<uint32_t> start(n3 + 2, 0), occ((n3 + 31) / 32, 0);
@@ -372,6 +389,87 @@ int rtm_scene_free(rtm_scene_dev* sd) {
     return RTM_OK;
 }
 
+// ---- rt_front.h orchestration ---------------------------------------------------------------------
+namespace {
+
+bool front_supported(const rtm_scene_dev* sd) {
+    return sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide;
+}
+
+// One frame as bands of rows; per band: round 0 (camera rays), then shade/trace rounds until no path is alive.
+int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, uint32_t occ_words, double* d_rgb, uint32_t* d_obj,
+                 uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream) {
+    const bool stats = d_cnt != nullptr;
+    const uint32_t tiles_x = (p->width + 7) / 8;
+    const size_t band_paths = (size_t)tiles_x * 64u * p->spp;  // paths of one 8-row band
+    if (band_paths > 0x3FFFFFFFu / 3u) return rtm_internal_fail(RTM_ERR_INVALID, "width x spp too large for one band of paths");
+    const uint32_t bands_total = (n_rows + 7) / 8;
+    uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / band_paths);
+    bands_per_chunk = std::min(bands_per_chunk, bands_total);
+    const size_t np_max = band_paths * bands_per_chunk;
+    if (np_max * 3u > 0xFFFFFFF0ull) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
+    // sub-queues (rt_front.h): the shade grid is a multiple of nq waves
+    const uint32_t nq = (uint32_t)g_num_cus * g_front_shade_waves_per_cu;  // one sub-list per shade wave
+    const uint32_t blocks_max = (uint32_t)((np_max + 63) / 64);
+    const uint32_t cap_l_max = ((blocks_max + nq - 1) / nq) * 64u;
+    // workspace layout (all sized for np_max)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t items_max = (size_t)nq * cap_l_max * 3u;
+    const size_t o_D = take(np_max * rtf::PF_COUNT * 8), o_rt = take(np_max * 3 * 8), o_itD = take(items_max * rtf::IT_DCOUNT * 8);
+    const size_t o_U = take(np_max * rtf::PU_COUNT * 4), o_rtri = take(np_max * 3 * 4), o_rm = take(np_max * 3 * 4);
+    const size_t o_itU = take(items_max * rtf::IU_COUNT * 4), o_l0 = take((size_t)nq * cap_l_max * 4), o_l1 = take((size_t)nq * cap_l_max * 4);
+    const size_t o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
+    if (off > g_front_ws.bytes) {
+        if (g_front_ws.base) HIP_TRY(hipFree(g_front_ws.base));
+        g_front_ws.base = nullptr;
+        g_front_ws.bytes = 0;
+        HIP_TRY(hipMalloc((void**)&g_front_ws.base, off));
+        g_front_ws.bytes = off;
+    }
+    char* const B = g_front_ws.base;
+    const uint32_t B_rounds = std::max<uint32_t>(1, (sd->view.n_lights + 1) / 2);
+    const uint32_t rounds = 2 + std::max<uint32_t>(p->max_bounces, 1) * B_rounds;
+    const dim3 block(256);
+    const uint32_t shade_wgs = nq / 4u;
+    const uint32_t trace_wgs = (uint32_t)g_num_cus * (uint32_t)RTM_FRONT_OCC;
+    for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk) {
+        const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
+        rtf::FrontArgs A{};
+        A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_bounces = p->max_bounces; A.seed = p->seed;
+        A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
+        A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
+        A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
+        A.cull = stats ? 0u : g_front_cull;
+        A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
+        A.occ_words = occ_words;
+        A.D = (double*)(B + o_D); A.res_t = (double*)(B + o_rt); A.itD = (double*)(B + o_itD);
+        A.U = (uint32_t*)(B + o_U); A.res_tri = (uint32_t*)(B + o_rtri); A.res_m = (uint32_t*)(B + o_rm);
+        A.itU = (uint32_t*)(B + o_itU);
+        A.nq = nq; A.cap_l = ((((A.np + 63u) / 64u) + nq - 1) / nq) * 64u; A.cap_i = A.cap_l * 3u; A.cap_items = nq * A.cap_i;
+        A.live[0] = (uint32_t*)(B + o_l0); A.live[1] = (uint32_t*)(B + o_l1); A.ctr = (uint32_t*)(B + o_ctr);
+        const uint32_t shade_wgs0 = shade_wgs;
+        for (uint32_t r = 0; r < rounds; ++r) {
+            if (r == 0) {
+                if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+                else hipLaunchKernelGGL((rtf::front_shade_kernel<false, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+            } else {
+                if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+                else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+            }
+            if (r + 1 < rounds) {  // the last round only finalises
+                if (stats) hipLaunchKernelGGL(rtf::front_trace_kernel<true>, dim3(trace_wgs), block, (size_t)occ_words * 4, stream, sd->view, A, d_cnt);
+                else hipLaunchKernelGGL(rtf::front_trace_kernel<false>, dim3(trace_wgs), block, (size_t)occ_words * 4, stream, sd->view, A, d_cnt);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(rtf::front_resolve_kernel, dim3((A.npix + 255) / 256), block, 0, stream, A, d_rgb);
+        HIP_TRY(hipGetLastError());
+    }
+    return RTM_OK;
+}
+}  // namespace
+
 int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, uint32_t* d_obj, uint32_t* d_tri,
                       rtm_stats* out_stats, void* stream_) {
     if (int rc = need_init()) return rc;
@@ -398,7 +496,13 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     static const uint32_t wgs_env = std::getenv("RTM_WGS_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("RTM_WGS_PER_CU"))) : 0u;
     const uint32_t wgs_per_cu = wgs_env ? wgs_env : (multi ? (uint32_t)RTM_MULTI_OCC : (uint32_t)RTM_WAVE_OCC);
     const uint32_t wave_wgs = std::min<uint32_t>((AW.n_tiles + 3) / 4, (uint32_t)g_num_cus * wgs_per_cu);
+    const bool front = !v1 && g_kernel == 2 && front_supported(sd);
+    int front_rc = RTM_OK;
     auto launch = [&](bool stats, unsigned long long* d_cnt) {
+        if (front) {
+            front_rc = render_front(sd, p, n_rows, AW.occ_words, d_rgb, d_obj, d_tri, stats ? d_cnt : nullptr, stream);
+            return front_rc == RTM_OK ? hipSuccess : hipErrorUnknown;
+        }
         if (v1) {
             if (stats) hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
             else hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
@@ -424,6 +528,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         (void)hipFree(d_cnt);
+        if (front_rc != RTM_OK) return front_rc;
         if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
         if (std::getenv("RTM_DIAG") && h[9])
             std::fprintf(stderr, "[rtm diag] S rounds %llu (avg %.1f lanes, %.0f cyc/round)  T steps %llu (avg %.1f lanes, %.0f cyc/step)  wave cycles: S %.1f%% T %.1f%% of %.3g\n",
@@ -441,7 +546,11 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         out_stats->cells_visited = h[6]; out_stats->tri_tests = h[7]; out_stats->model_hits = h[8];
         return RTM_OK;
     }
-    HIP_TRY(launch(false, nullptr));
+    {
+        const hipError_t e = launch(false, nullptr);
+        if (front_rc != RTM_OK) return front_rc;
+        HIP_TRY(e);
+    }
     return RTM_OK;
 }
 

@@ -1,0 +1,759 @@
+// rt_front.h -- the render path as ray "fronts": every sample path of a band of pixel rows advances one path
+// vertex per round, and each round is two kernels over compacted lists in HBM
+//     shade  (one lane per live path): consume the finished queries in the reference's order, create the next
+//            vertex, produce its rays -- bounce ray and up to two shadow rays at once -- including the analytic
+//            primitives, the slab test and the DDA initialisation (main.rs:57-132, core.rs:68-125,183-210);
+//     trace  (persistent lanes fed from a queue): the 3D-DDA walk and the triangle tests (core.rs:129-167,
+//            model.rs:43-74) for the rays that entered a model's box.
+// Why (DESIGN.md "Kernel", measurements in profiles/): the single-kernel state machines (rt_wave.h, rt_multi.h)
+// are bound by VALU issue at 25-45 % lane utilisation, because a wave always holds a mix of lanes that shade,
+// walk and test.  Sorting by activity needs a pool much larger than a wave; 288 GB of HBM3E hold the state of
+// tens of millions of paths, so the sort is done through memory: the shade kernel runs with every lane doing
+// the same thing, and the trace kernel's lanes only ever walk or test -- a finished lane pulls the next ray from
+// the queue (a dozen coalesced loads) instead of waiting for a set-up round.
+// The order in which results are COMBINED is the reference's (lights in order, then the surface term, then the
+// attenuation, samples in order); only the order in which rays are traced changes, and every query is a pure
+// function of its ray.  The arithmetic of each block is the op sequence of rt_device.h: bit-identical results.
+#pragma once
+#include "rt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace rtf {
+using namespace rtd;
+
+#ifndef RTM_FRONT_OCC
+#define RTM_FRONT_OCC 4  // waves per SIMD the trace kernel's register allocation must leave room for
+#endif
+#ifndef RTM_FWALK_UNROLL
+#define RTM_FWALK_UNROLL 2
+#endif
+#ifndef RTM_FTRI_WIDE
+#define RTM_FTRI_WIDE 4
+#endif
+constexpr int kBlock = 256;
+constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 10 bits each, biased by one
+
+// per-path state, structure of arrays: double field f of path p is D[f * np + p], u32 field U[f * np + p]
+enum : int {
+    PF_COL = 0,    // colour accumulated along the path (main.rs:59)
+    PF_ATT = 3,    // attenuation so far
+    PF_O = 4,      // origin shared by the path's queries: the camera or the vertex being shaded
+    PF_D0 = 7,     // direction of the camera / bounce query
+    PF_BA0 = 10,   // its closest analytic hit (spheres, planes)
+    PF_SD = 11,    // directions of the two shadow queries
+    PF_SBA = 17,   // their closest analytic hits
+    PF_SDL2 = 19,  // squared distances to their lights
+    PF_SC = 21,    // what each adds to the diffuse sum if it is not occluded (main.rs:96-102)
+    PF_DIFF = 27,  // diffuse sum so far (scenes with more than two lights)
+    PF_NRM = 30,   // shading normal (scenes with more than two lights)
+    PF_COUNT = 33
+};
+enum : int { PU_FL = 0, PU_CTR = 1, PU_HOBJ = 2, PU_HMAT = 3, PU_HKP = 4, PU_MAT = 5, PU_COUNT = 6 };
+enum : uint32_t {
+    FB_HASV = 1u,                              // a shaded vertex waits for its shadow results
+    FB_FOUND0 = 2u, FB_FOUND1 = 4u, FB_FOUND2 = 8u,  // query j has an analytic hit
+    FB_TQ0 = 16u, FB_TQ1 = 32u, FB_TQ2 = 64u,        // query j went to the trace kernel: res_*[3p+j] holds its model hit
+    FB_C1 = 128u, FB_C2 = 256u,                      // shadow query j faces its light (eff > 0.001): PF_SC is valid
+    FB_NSH_SHIFT = 9u                                // two bits: shadow queries in flight (0..2)
+};
+// trace items, structure of arrays over the item index
+enum : int { IT_O = 0, IT_D = 3, IT_TM = 6, IT_TD = 9, IT_DCOUNT = 12 };
+enum : int { IU_CELL = 0, IU_Q = 1, IU_M = 2, IU_COUNT = 3 };
+enum : uint32_t { IM_SX = 1u << 16, IM_SY = 1u << 17, IM_SZ = 1u << 18 };
+// device counters, one set per sub-queue (each written by the one wave that owns the sub-queue)
+enum : int { CT_LIVE0 = 0, CT_LIVE1 = 1, CT_ITEMS = 2, CT_STRIDE = 4 };
+
+struct FrontArgs {
+    uint32_t W, H, spp, max_bounces;
+    uint64_t seed;
+    uint32_t row_begin, row_stride, flags;
+    uint32_t row0, rows;        // this band: local rows [row0, row0 + rows)
+    uint32_t tiles_x, n_tiles;  // 8x8 pixel tiles over W x rows; pixel ids are tile-major
+    uint32_t npix, np;          // npix = n_tiles * 64 (ragged tiles padded), np = npix * spp paths, p = sample * npix + pixel id
+    uint32_t cull;              // 1: shadow queries that cannot contribute (eff <= 0.001) are not traced
+    uint32_t refill;            // trace kernel: fetch new items when at least this many lanes of a wave are idle
+    uint32_t t_test_frac, t_min_lanes;
+    uint32_t occ_words;
+    double* D;
+    uint32_t* U;
+    double* res_t;
+    uint32_t* res_tri;
+    uint32_t* res_m;
+    double* itD;
+    uint32_t* itU;
+    uint32_t cap_items;         // nq * cap_i: stride of the item arrays
+    uint32_t nq;                // sub-queues: wave w of the shade kernel reads live sub-list w % nq and appends to the same one
+    uint32_t cap_l, cap_i;      // capacity of one live sub-list / one item sub-queue (cap_i = 3 * cap_l)
+    uint32_t* live[2];          // [nq][cap_l] each
+    uint32_t* ctr;              // [nq][CT_STRIDE]
+};
+
+RTM_DEV uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+        const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+template <bool STATS>
+RTM_DEV void flush_counters(const Counters& cnt, unsigned long long* out_cnt) {
+    if (STATS) {
+        for (int i = 0; i < 9; ++i) {
+            const uint64_t v = wave_sum(cnt.v[i]);
+            if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out_cnt + i, (unsigned long long)v);
+        }
+    }
+}
+
+// ================================================================================================
+// shade: round 0 creates the camera rays (main.rs:160-168); later rounds consume and re-issue
+template <bool STATS, bool ROUND0>
+__global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
+                                                              uint32_t* __restrict__ out_tri, unsigned long long* __restrict__ out_cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // one sub-list per wave (the grid has exactly nq waves): lists and queues are appended to without atomics.
+    // (Device-scope atomics resolve outside the per-XCD L2 on this part; ~10 ns each when they share an address,
+    // which made a single queue counter the bottleneck of both kernels.)
+    const uint32_t sq = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    uint32_t* const my_ctr = A.ctr + (size_t)sq * CT_STRIDE;
+    uint32_t n_live_local = 0, n_items_local = 0;  // wave-uniform
+    // round 0: sub-list sq is the wave-sized blocks g = k * nq + sq of the identity list
+    const uint32_t blocks_total = (A.np + 63u) / 64u;
+    const uint32_t n_in_list = ROUND0 ? ((blocks_total + A.nq - 1u - sq) / A.nq) * 64u : my_ctr[round & 1u];
+    const uint32_t* __restrict__ live_in = A.live[round & 1u] + (size_t)sq * A.cap_l;
+    uint32_t* __restrict__ live_out = A.live[(round + 1u) & 1u] + (size_t)sq * A.cap_l;
+    const size_t np = A.np;
+    double* const D = A.D;
+    uint32_t* const U = A.U;
+    const int K = (int)A.max_bounces;
+    const uint32_t nL = S.n_lights;
+    Counters cnt;
+    if (STATS)
+        for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
+
+    for (uint32_t k = 0; k * 64u < n_in_list; ++k) {  // wave-uniform trip count
+        const uint32_t idx = k * 64u + lane;
+        bool valid = idx < n_in_list;
+        uint32_t p = 0;
+        if (ROUND0) {
+            p = (k * A.nq + sq) * 64u + lane;
+            valid = p < A.np;
+            if (!valid) p = 0;
+        } else if (valid) {
+            p = live_in[idx];
+        }
+        auto ldD = [&](int f) -> double { return D[(size_t)f * np + p]; };
+        auto stD = [&](int f, double v) { D[(size_t)f * np + p] = v; };
+        auto ldD3 = [&](int f) -> V3 { return mk(ldD(f), ldD(f + 1), ldD(f + 2)); };
+        auto stD3 = [&](int f, V3 v) { stD(f, v.x); stD(f + 1, v.y); stD(f + 2, v.z); };
+        auto ldU = [&](int f) -> uint32_t { return U[(size_t)f * np + p]; };
+        auto stU = [&](int f, uint32_t v) { U[(size_t)f * np + p] = v; };
+
+        // path -> sample, pixel
+        const uint32_t s = p / A.npix, pid = p - s * A.npix;
+        const uint32_t tile = pid >> 6, in = pid & 63u;
+        const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
+        const uint32_t lyc = (tile / A.tiles_x) * 8u + (in >> 3);
+        if (ROUND0 && !(x < A.W && lyc < A.rows)) valid = false;  // padding of a ragged tile: never alive
+        const uint32_t ly = A.row0 + lyc;
+        const uint32_t yy = A.row_begin + ly * A.row_stride;
+        const uint32_t pixel = x + A.W * yy;  // main.rs:160-161,177
+
+        // what this round produces
+        bool cont = false;                      // the path stays alive
+        bool go0 = false, go1 = false, go2 = false;
+        V3 o = mk(0, 0, 0), dir0 = mk(0, 0, 1), nn = mk(0, 0, 1);
+        uint32_t fl = 0, bounce = 0, li = 0, n_sh = 0;
+        uint32_t h_obj = kNoId, h_mat = 0, h_kp = 0, h_tri = kNoId;
+        double best0 = 0.0;
+        bool found0 = false;
+
+        if (valid) {
+            if (ROUND0) {
+                double xo = 0.0, yo = 0.0;
+                if (!(A.flags & RTM_FLAG_ZERO_JITTER)) {  // main.rs:162-163
+                    uint32_t ra[4];
+                    philox(A.seed, pixel, s, 0u, ra);
+                    xo = u01(ra[0], ra[1]) * (0.5 - -0.5) + -0.5;
+                    yo = u01(ra[2], ra[3]) * (0.5 - -0.5) + -0.5;
+                }
+                const double u = ((double)x + xo - (double)A.W * 0.5) / (double)A.W;   // main.rs:165
+                const double v = ((double)yy + yo - (double)A.H * 0.5) / (double)A.H;  // main.rs:166
+                dir0 = normalize(ld3(S.cam_fwd) * S.cam_zoom + ld3(S.cam_up) * v + ld3(S.cam_right) * u);  // camera.rs:47
+                o = ld3(S.cam_pos);
+                stD3(PF_COL, mk(0, 0, 0));
+                stD(PF_ATT, 1.0);
+                stD3(PF_O, o);
+                go0 = true;
+                cont = true;
+                if (STATS) cnt.v[C_CAM]++;
+            } else {
+                fl = ldU(PU_FL);
+                const uint32_t ctr = ldU(PU_CTR);
+                bounce = ctr & 0xFFFFu;
+                li = ctr >> 16;
+                o = ldD3(PF_O);
+                // ---- 0. decisions
+                const bool a_v = (fl & FB_HASV) != 0u;
+                const uint32_t n_in = a_v ? ((fl >> FB_NSH_SHIFT) & 3u) : 0u;  // shadow results to consume
+                const bool a_more = a_v && li + n_in < nL;                      // further lights: another batch
+                const bool a_fin = a_v && !a_more;                              // the vertex is complete (main.rs:107-125)
+                const bool a_end = a_fin && (int)bounce + 1 >= K;               // ... and it was the last one allowed
+                const bool b_take = !a_more && !a_end;                          // the path query's result is due
+                const uint32_t q = p * 3u;
+                // ---- 1. the path query: analytic hit, then the model hit the trace kernel found (core.rs:75-83)
+                if (b_take) {
+                    best0 = ldD(PF_BA0);
+                    found0 = (fl & FB_FOUND0) != 0u;
+                    h_obj = ldU(PU_HOBJ); h_mat = ldU(PU_HMAT); h_kp = ldU(PU_HKP);
+                    if (fl & FB_TQ0) {
+                        const uint32_t m = A.res_m[q];
+                        if (m != kNoId) {
+                            const double t = A.res_t[q];
+                            const uint32_t mobj = S.models[m].obj;
+                            if (!(t <= kEps) && (t < best0 || (found0 && t == best0 && mobj < h_obj))) {
+                                best0 = t; found0 = true;
+                                h_obj = mobj; h_mat = S.models[m].mat; h_kp = (2u << 30) | m; h_tri = A.res_tri[q];
+                            }
+                        }
+                    }
+                }
+                const bool b_hit = b_take && found0, b_miss = b_take && !found0;
+                const bool end_sample = a_end || b_miss;
+                const uint32_t mat_old = a_fin ? ldU(PU_MAT) : 0u;
+                const bool metal_old = S.materials[(size_t)mat_old * 4 + 3] != 0.0;
+                const uint32_t mat_new = b_hit ? h_mat : mat_old;
+                const bool metal_new = S.materials[(size_t)mat_new * 4 + 3] != 0.0;
+                const uint32_t bounce_new = bounce + (a_fin ? 1u : 0u);  // index of the vertex a hit creates
+                const bool plastic_hit = b_hit && !metal_new;
+                uint32_t ra[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+                if (plastic_hit) {  // Vec3::random() of this bounce (vec3.rs:160-162)
+                    philox(A.seed, pixel, s, 1u + 2u * bounce_new, ra);
+                    philox(A.seed, pixel, s, 2u + 2u * bounce_new, rb);
+                }
+                // ---- 2. shadow results of the pending vertex, in light order (main.rs:86-104); o == P
+                V3 diff = mk(0, 0, 0);
+                if (n_in > 0u) {
+                    if (li > 0u) diff = ldD3(PF_DIFF);
+                    auto shade = [&](const uint32_t j) __attribute__((always_inline)) {
+                        if (j < n_in && (fl & (FB_C1 << j))) {  // a query that cannot contribute is not looked at
+                            double best = ldD(PF_SBA + (int)j);
+                            bool found = (fl & (FB_FOUND1 << j)) != 0u;
+                            if (fl & (FB_TQ1 << j)) {
+                                const uint32_t m = A.res_m[q + 1u + j];
+                                const double t = A.res_t[q + 1u + j];
+                                if (m != kNoId && !(t <= kEps) && t < best) { best = t; found = true; }
+                            }
+                            bool occluded = false;
+                            if (found) occluded = sqdist(ray_at(o, ldD3(PF_SD + 3 * (int)j), best), o) <= ldD(PF_SDL2 + (int)j);
+                            if (!occluded) diff = diff + ldD3(PF_SC + 3 * (int)j);
+                        }
+                    };
+                    shade(0u);
+                    shade(1u);
+                    li += n_in;
+                    if (a_more) stD3(PF_DIFF, diff);
+                }
+                // ---- 3. end of the light loop: the surface's colour, attenuation (main.rs:107-125)
+                V3 col = mk(0, 0, 0);
+                double att = 0.0;
+                if (a_fin || b_miss) { col = ldD3(PF_COL); att = ldD(PF_ATT); }
+                if (a_fin) {
+                    const double* mp = S.materials + (size_t)mat_old * 4;
+                    col = col + ld3(mp) * att * (diff * (metal_old ? 0.2 : 0.9));
+                    att = att * (metal_old ? 0.8 : 0.1);
+                    ++bounce;
+                    fl &= ~FB_HASV;
+                }
+                // ---- 4. the path query's result
+                if (b_take && bounce == 0u && s == 0u) {
+                    const size_t oi = (size_t)ly * A.W + x;
+                    if (out_obj) out_obj[oi] = found0 ? h_obj : kNoId;
+                    if (out_tri) out_tri[oi] = found0 ? h_tri : kNoId;
+                }
+                if (b_miss) col = col + mk(1, 1, 1) * att;  // main.rs:127
+                if (a_fin || b_miss) { stD3(PF_COL, col); stD(PF_ATT, att); }
+                bool norm0 = false;
+                if (b_hit) {
+                    // surface point and shading normal (core.rs:89,169-177,195,209; main.rs:68-73)
+                    const V3 d = ldD3(PF_D0);
+                    const V3 P = ray_at(o, d, best0);
+                    const uint32_t kind = h_kp >> 30, prim = h_kp & 0x3FFFFFFFu;
+                    V3 raw;
+                    if (kind == 0u) raw = ray_at(o, d, best0) - ld3(S.spheres + (size_t)prim * 4);
+                    else if (kind == 1u) raw = ld3(S.planes + (size_t)prim * 4);  // used as written, not normalised
+                    else raw = model_normal_raw(S.models[prim], h_tri, P);
+                    nn = normalize(raw);
+                    if (kind == 1u) nn = raw;
+                    if (dot(d, nn) > 0.001) nn = nn * -1.0;
+                    // bounce direction (main.rs:50-55): metal reflects (not renormalised, vec3.rs:172-175); plastic is
+                    // normalize(n + random())
+                    const V3 rnd = mk(u01(ra[0], ra[1]) * (1.0 - 0.0) + 0.0, u01(ra[2], ra[3]) * (1.0 - 0.0) + 0.0,
+                                      u01(rb[0], rb[1]) * (1.0 - 0.0) + 0.0);
+                    const V3 refl = d - nn * 2.0 * dot(d, nn);
+                    const V3 dif = nn + rnd;
+                    dir0 = metal_new ? refl : dif;
+                    norm0 = !metal_new;
+                    stU(PU_MAT, mat_new);
+                    o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
+                    stD3(PF_O, o);
+                    if (nL > 2u) stD3(PF_NRM, nn);
+                    li = 0;
+                    fl |= FB_HASV;
+                } else if (a_more) {
+                    nn = ldD3(PF_NRM);
+                }
+                // ---- 5. the new queries
+                go0 = b_hit && (int)bounce + 1 < K;
+                const bool sh = b_hit || a_more;
+                n_sh = sh ? (nL - li < 2u ? nL - li : 2u) : 0u;
+                go1 = n_sh > 0u;
+                go2 = n_sh > 1u;
+                {
+                    const V3 nd = normalize(dir0);  // vec3.rs:213-215: three divisions by the length
+                    dir0 = norm0 ? nd : dir0;
+                }
+                if (STATS && go0) cnt.v[C_BOUNCE]++;
+                if (STATS) cnt.v[C_SHADOW] += n_sh;
+                cont = !end_sample;
+                // flags that describe the queries are rebuilt below; slot 0's stay while its result is still pending
+                fl &= a_more ? (FB_HASV | FB_FOUND0 | FB_TQ0) : FB_HASV;
+            }
+        }
+
+        // ---- a query: analytic primitives (core.rs:183-210), slab test and DDA set-up of the first model whose box
+        //      the ray meets (box3D.rs:64-93, core.rs:95-125); that model and the following ones are the trace kernel's
+        auto issue = [&](const uint32_t j, const bool go, const V3 dir) __attribute__((always_inline)) {
+            bool item = false;
+            int ix = 0, iy = 0, iz = 0;
+            double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
+            uint32_t mword = 0;
+            if (go) {
+                double best = __builtin_inf();
+                bool found = false;
+                uint32_t b_obj = kNoId, b_mat = 0, b_kp = 0;
+                auto consider = [&](double t, uint32_t obj, uint32_t mt, uint32_t kp) __attribute__((always_inline)) {
+                    if (t <= kEps) return;  // core.rs:75-77
+                    if (t < best || (found && t == best && obj < b_obj)) {
+                        best = t; found = true;
+                        b_obj = obj; b_mat = mt; b_kp = kp;
+                    }
+                };
+                const double a = dot(dir, dir);
+                for (uint32_t i = 0; i < S.n_spheres; ++i) {
+                    if (STATS) cnt.v[C_SPHERE]++;
+                    const double* sp = S.spheres + (size_t)i * 4;
+                    const V3 oc = o - ld3(sp);
+                    const double b = 2.0 * dot(dir, oc);
+                    const double c = dot(oc, oc) - sp[3] * sp[3];
+                    const double disc = b * b - 4.0 * a * c;
+                    if (disc < 0.0) continue;
+                    const double t = (-b - __builtin_sqrt(disc)) / (2.0 * a);
+                    consider(t, S.sph_ids[i * 2 + 1], S.sph_ids[i * 2], i);
+                }
+                for (uint32_t i = 0; i < S.n_planes; ++i) {
+                    if (STATS) cnt.v[C_PLANE]++;
+                    const double* pp = S.planes + (size_t)i * 4;
+                    const V3 pn = ld3(pp);
+                    const double dv = dot(pn, dir);
+                    if (fabs(dv) < kEps) continue;
+                    const V3 center = pn * pp[3];
+                    const double t = dot(center - o, pn) / dv;
+                    if (t < kEps) continue;
+                    consider(t, S.pl_ids[i * 2 + 1], S.pl_ids[i * 2], (1u << 30) | i);
+                }
+                if (j == 0u) {
+                    stD3(PF_D0, dir);
+                    stD(PF_BA0, best);
+                    stU(PU_HOBJ, b_obj); stU(PU_HMAT, b_mat); stU(PU_HKP, b_kp);
+                } else {
+                    stD3(PF_SD + 3 * ((int)j - 1), dir);
+                    stD(PF_SBA + (int)j - 1, best);
+                }
+                if (found) fl |= FB_FOUND0 << j;
+                {
+                    for (uint32_t m = 0; m < S.n_models && !item; ++m) {
+                        const RtmDevModel& M = S.models[m];
+                        if (STATS) cnt.v[C_BBOX]++;
+                        const double fx = 1.0 / dir.x, fy = 1.0 / dir.y, fz = 1.0 / dir.z;
+                        const double t1 = (M.bmin[0] - o.x) * fx, t2 = (M.bmax[0] - o.x) * fx;
+                        const double t3 = (M.bmin[1] - o.y) * fy, t4 = (M.bmax[1] - o.y) * fy;
+                        const double t5 = (M.bmin[2] - o.z) * fz, t6 = (M.bmax[2] - o.z) * fz;
+                        const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
+                        const double tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
+                        if (!(tmax < 0.0 || tmin > tmax)) {
+                            const V3 P0 = ray_at(o, dir, tmin);
+                            const int n = (int)M.n;
+                            ix = cell_coord((P0.x - M.bmin[0]) / M.cell[0], n);
+                            iy = cell_coord((P0.y - M.bmin[1]) / M.cell[1], n);
+                            iz = cell_coord((P0.z - M.bmin[2]) / M.cell[2], n);
+                            const int sx = dir.x > 0.0 ? 1 : -1, sy = dir.y > 0.0 ? 1 : -1, sz = dir.z > 0.0 ? 1 : -1;
+                            const double nbx = (M.bmin[0] + M.hc2[0] * ((double)(ix + (sx > 0 ? 1 : 0)) + 0.5)) - M.hc[0];
+                            const double nby = (M.bmin[1] + M.hc2[1] * ((double)(iy + (sy > 0 ? 1 : 0)) + 0.5)) - M.hc[1];
+                            const double nbz = (M.bmin[2] + M.hc2[2] * ((double)(iz + (sz > 0 ? 1 : 0)) + 0.5)) - M.hc[2];
+                            tmx = (nbx - P0.x) / dir.x; tmy = (nby - P0.y) / dir.y; tmz = (nbz - P0.z) / dir.z;
+                            tdx = ((double)sx * M.cell[0]) / dir.x;
+                            tdy = ((double)sy * M.cell[1]) / dir.y;
+                            tdz = ((double)sz * M.cell[2]) / dir.z;
+                            mword = m | (sx > 0 ? IM_SX : 0u) | (sy > 0 ? IM_SY : 0u) | (sz > 0 ? IM_SZ : 0u);
+                            item = true;
+                        }
+                    }
+                    if (item) fl |= FB_TQ0 << j;
+                }
+            }
+            // append to the wave's trace sub-queue
+            const unsigned long long want = __ballot(item);
+            if (want) {
+                const uint32_t at = n_items_local;
+                n_items_local += (uint32_t)__popcll(want);
+                if (item) {
+                    const size_t it = (size_t)sq * A.cap_i + at + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                    const size_t cap = A.cap_items;
+                    double* const I = A.itD;
+                    I[(IT_O + 0) * cap + it] = o.x; I[(IT_O + 1) * cap + it] = o.y; I[(IT_O + 2) * cap + it] = o.z;
+                    I[(IT_D + 0) * cap + it] = dir.x; I[(IT_D + 1) * cap + it] = dir.y; I[(IT_D + 2) * cap + it] = dir.z;
+                    I[(IT_TM + 0) * cap + it] = tmx; I[(IT_TM + 1) * cap + it] = tmy; I[(IT_TM + 2) * cap + it] = tmz;
+                    I[(IT_TD + 0) * cap + it] = tdx; I[(IT_TD + 1) * cap + it] = tdy; I[(IT_TD + 2) * cap + it] = tdz;
+                    A.itU[(size_t)IU_CELL * cap + it] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
+                    A.itU[(size_t)IU_Q * cap + it] = p * 3u + j;
+                    A.itU[(size_t)IU_M * cap + it] = mword;
+                }
+            }
+        };
+        issue(0u, go0, dir0);
+        {
+            // shadow rays to lights li, li+1 (main.rs:80-85) and what each would add to the diffuse sum (main.rs:96-102)
+            auto shadow = [&](const uint32_t j, const bool go) __attribute__((always_inline)) {
+                V3 dir = mk(0, 0, 1);
+                bool trace = false;
+                if (go) {
+                    const double* L = S.lights + (size_t)(li + j) * 8;
+                    const V3 lp = ld3(L);
+                    dir = normalize(lp - o);
+                    const double dl2 = sqdist(o, lp);
+                    stD(PF_SDL2 + (int)j, dl2);
+                    const double eff = dot(dir, nn);
+                    const bool lit = eff > 0.001;
+                    if (lit) {
+                        const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
+                        const double decay = 1.0 / dd;
+                        stD3(PF_SC + 3 * (int)j, ld3(L + 3) * decay * eff);
+                        fl |= FB_C1 << j;
+                    }
+                    trace = lit || !A.cull;
+                }
+                issue(1u + j, go && trace, dir);  // (the host turns culling off when exact work counters are wanted)
+            };
+            shadow(0u, go1);
+            shadow(1u, go2);
+        }
+        if (valid && cont) {
+            stU(PU_FL, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT));
+            stU(PU_CTR, bounce | (li << 16));
+        }
+        {
+            const unsigned long long alive = __ballot(valid && cont);
+            if (valid && cont) live_out[n_live_local + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull))] = p;
+            n_live_local += (uint32_t)__popcll(alive);
+        }
+    }
+    if (lane == 0) {
+        my_ctr[(round + 1u) & 1u] = n_live_local;
+        my_ctr[CT_ITEMS] = n_items_local;
+    }
+    flush_counters<STATS>(cnt, out_cnt);
+}
+
+// ================================================================================================
+// trace: persistent lanes; a lane holds one ray and only ever walks cells or tests triangles
+enum : uint32_t { TS_IDLE = 0, TS_ENTER = 1, TS_TRAV = 2 };
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmDevScene S, FrontArgs A, unsigned long long* __restrict__ out_cnt) {
+    extern __shared__ uint32_t occ_lds[];  // [A.occ_words]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    {  // stage the occupancy bitmaps (models back to back; those that do not fit stay in HBM)
+        uint32_t base = 0;
+        for (uint32_t m = 0; m < S.n_models; ++m) {
+            const uint32_t n = S.models[m].n;
+            const uint32_t words = (n * n * n + 31u) >> 5;
+            if (base + words > A.occ_words) break;
+            const gptr<uint32_t> src = as_global(S.models[m].occupancy);
+            for (uint32_t i = tid; i < words; i += kBlock) occ_lds[base + i] = src[i];
+            base += words;
+        }
+    }
+    __syncthreads();
+    Counters cnt;
+    if (STATS)
+        for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
+    const size_t cap = A.cap_items;
+    // the wave's position in the queue: it owns sub-queues sq, sq + waves, sq + 2 waves, ... and reads each in order
+    const uint32_t trace_waves = gridDim.x * (kBlock / 64);
+    uint32_t sq = blockIdx.x * (kBlock / 64) + (tid >> 6);
+    uint32_t pool_next = 0, pool_end = 0;  // unread items of the current sub-queue
+    if (sq < A.nq) {
+        pool_next = sq * A.cap_i;
+        pool_end = pool_next + A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
+    }
+    const gptr<double> I = as_global(A.itD);
+    const gptr<uint32_t> IU = as_global(A.itU);
+
+    uint32_t st = TS_IDLE, model_i = 0, q = 0, sgn = 0;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    int ix = 0, iy = 0, iz = 0;
+    double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
+    uint32_t k = 0, k_end = 0, m_tri = 0;
+    double m_t = 0.0;
+    bool have = false, fresh = false, open = false;
+    double bt = 0.0;  // closest model hit of this ray so far, over the models visited (core.rs:79-83)
+    uint32_t bm = kNoId, btri = kNoId, bobj = kNoId;
+    bool exhausted = sq >= A.nq;
+
+    auto finish_ray = [&]() __attribute__((always_inline)) {
+        A.res_t[q] = bt;
+        A.res_tri[q] = btri;
+        A.res_m[q] = bm;
+        st = TS_IDLE;
+    };
+    auto model_result = [&](const bool hit, const uint32_t m, const uint32_t mobj) __attribute__((always_inline)) {
+        if (hit && !(m_t <= kEps) && (bm == kNoId || m_t < bt || (m_t == bt && mobj < bobj))) {
+            bt = m_t; bm = m; btri = m_tri; bobj = mobj;
+        }
+    };
+#define RTF_DDA_ADVANCE()                                                      \
+    do {                                                                       \
+        const bool ax_ = (tmx < tmy) && (tmx < tmz);                           \
+        const bool ay_ = !(tmx < tmy) && (tmy < tmz);                          \
+        const bool az_ = !ax_ && !ay_;                                         \
+        ix += ax_ ? ((sgn & IM_SX) ? 1 : -1) : 0;                              \
+        iy += ay_ ? ((sgn & IM_SY) ? 1 : -1) : 0;                              \
+        iz += az_ ? ((sgn & IM_SZ) ? 1 : -1) : 0;                              \
+        const double nx_ = tmx + tdx, ny_ = tmy + tdy, nz_ = tmz + tdz;        \
+        tmx = ax_ ? nx_ : tmx;                                                 \
+        tmy = ay_ ? ny_ : tmy;                                                 \
+        tmz = az_ ? nz_ : tmz;                                                 \
+    } while (0)
+
+    for (;;) {
+        unsigned long long idle = __ballot(st == TS_IDLE);
+        unsigned long long busy = __ballot(st != TS_IDLE);
+        // ---- refill: idle lanes take the next items of the wave's block, in order
+        if (!exhausted && ((uint32_t)__popcll(idle) >= A.refill || !busy)) {
+            for (;;) {
+                idle = __ballot(st == TS_IDLE);
+                if (!idle) break;
+                if (pool_next == pool_end) {  // next sub-queue of this wave
+                    sq += trace_waves;
+                    if (sq >= A.nq) { exhausted = true; break; }
+                    pool_next = sq * A.cap_i;
+                    pool_end = pool_next + A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
+                    continue;
+                }
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t avail = pool_end - pool_next;
+                if (st == TS_IDLE && rank < avail) {
+                    const size_t it = (size_t)pool_next + rank;
+                    o = mk(I[(IT_O + 0) * cap + it], I[(IT_O + 1) * cap + it], I[(IT_O + 2) * cap + it]);
+                    d = mk(I[(IT_D + 0) * cap + it], I[(IT_D + 1) * cap + it], I[(IT_D + 2) * cap + it]);
+                    tmx = I[(IT_TM + 0) * cap + it]; tmy = I[(IT_TM + 1) * cap + it]; tmz = I[(IT_TM + 2) * cap + it];
+                    tdx = I[(IT_TD + 0) * cap + it]; tdy = I[(IT_TD + 1) * cap + it]; tdz = I[(IT_TD + 2) * cap + it];
+                    const uint32_t cw = IU[(size_t)IU_CELL * cap + it];
+                    ix = (int)(cw & 1023u) - 1; iy = (int)((cw >> 10) & 1023u) - 1; iz = (int)((cw >> 20) & 1023u) - 1;
+                    q = IU[(size_t)IU_Q * cap + it];
+                    const uint32_t mw = IU[(size_t)IU_M * cap + it];
+                    model_i = mw & 0xFFFFu;
+                    sgn = mw;
+                    have = false; fresh = true; open = false;
+                    bm = kNoId; btri = kNoId; bobj = kNoId; bt = 0.0;
+                    st = TS_TRAV;
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                pool_next += want < avail ? want : avail;
+            }
+            busy = __ballot(st != TS_IDLE);
+        }
+        if (!busy) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- rays that have left a model and have further models to visit (scenes with several models)
+        if (__ballot(st == TS_ENTER)) {
+            for (uint32_t m = 0; m < S.n_models; ++m) {
+                const RtmDevModel& M = S.models[m];
+                if (st == TS_ENTER && model_i == m) {
+                    if (STATS) cnt.v[C_BBOX]++;
+                    const double fx = 1.0 / d.x, fy = 1.0 / d.y, fz = 1.0 / d.z;
+                    const double t1 = (M.bmin[0] - o.x) * fx, t2 = (M.bmax[0] - o.x) * fx;
+                    const double t3 = (M.bmin[1] - o.y) * fy, t4 = (M.bmax[1] - o.y) * fy;
+                    const double t5 = (M.bmin[2] - o.z) * fz, t6 = (M.bmax[2] - o.z) * fz;
+                    const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
+                    const double tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
+                    if (tmax < 0.0 || tmin > tmax) {
+                        model_i = m + 1;
+                    } else {
+                        const V3 P0 = ray_at(o, d, tmin);
+                        const int n = (int)M.n;
+                        ix = cell_coord((P0.x - M.bmin[0]) / M.cell[0], n);
+                        iy = cell_coord((P0.y - M.bmin[1]) / M.cell[1], n);
+                        iz = cell_coord((P0.z - M.bmin[2]) / M.cell[2], n);
+                        const int sx = d.x > 0.0 ? 1 : -1, sy = d.y > 0.0 ? 1 : -1, sz = d.z > 0.0 ? 1 : -1;
+                        const double nbx = (M.bmin[0] + M.hc2[0] * ((double)(ix + (sx > 0 ? 1 : 0)) + 0.5)) - M.hc[0];
+                        const double nby = (M.bmin[1] + M.hc2[1] * ((double)(iy + (sy > 0 ? 1 : 0)) + 0.5)) - M.hc[1];
+                        const double nbz = (M.bmin[2] + M.hc2[2] * ((double)(iz + (sz > 0 ? 1 : 0)) + 0.5)) - M.hc[2];
+                        tmx = (nbx - P0.x) / d.x; tmy = (nby - P0.y) / d.y; tmz = (nbz - P0.z) / d.z;
+                        tdx = ((double)sx * M.cell[0]) / d.x;
+                        tdy = ((double)sy * M.cell[1]) / d.y;
+                        tdz = ((double)sz * M.cell[2]) / d.z;
+                        sgn = (sx > 0 ? IM_SX : 0u) | (sy > 0 ? IM_SY : 0u) | (sz > 0 ? IM_SZ : 0u);
+                        have = false; fresh = true; open = false;
+                        st = TS_TRAV;
+                    }
+                }
+            }
+            if (st == TS_ENTER) finish_ray();  // no model left
+        }
+        const unsigned long long traversing = __ballot(st == TS_TRAV);
+        if (!traversing) continue;
+        // ---- traversal: lanes in the same model as the first traversing lane step together (mm is wave-uniform)
+        const int first_t = __ffsll((long long)traversing) - 1;
+        const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)model_i, first_t);
+        uint32_t occ_base = 0;  // LDS word offset of this model's bitmap, or 0xFFFFFFFF when it stayed in HBM
+        for (uint32_t j = 0; j <= mm; ++j) {
+            const uint32_t nj = S.models[j].n;
+            const uint32_t words = (nj * nj * nj + 31u) >> 5;
+            if (occ_base + words > A.occ_words) { occ_base = 0xFFFFFFFFu; break; }
+            if (j < mm) occ_base += words;
+        }
+        const RtmDevModel& M = S.models[mm];
+        const uint32_t n = M.n, M_obj = M.obj;
+        const gptr<uint32_t> cell_start = as_global(M.cell_start), tri_idx = as_global(M.tri_idx);
+        const gptr<double> tri_pos = as_global(M.tri_pos);
+        const gptr<uint32_t> occ_glb = as_global(M.occupancy);
+        const bool occ_in_lds = occ_base != 0xFFFFFFFFu;
+        const bool last_model = mm + 1u >= S.n_models;
+        for (;;) {
+            // A traversing lane is either WALKING (one DDA step and one bitmap probe per cell) or TESTING (its
+            // cell's list is open); each iteration runs one of the two activities, whichever has the lanes.
+            bool mine = st == TS_TRAV && model_i == mm;
+            if (mine && !open && have) {  // core.rs:147-149: the first cell with any accepted hit ends the walk
+                if (STATS) cnt.v[C_MHIT]++;
+                model_result(true, mm, M_obj);
+                model_i = mm + 1;
+                if (last_model) finish_ray(); else st = TS_ENTER;
+                mine = false;
+            }
+            const uint32_t nW = (uint32_t)__popcll(__ballot(mine && !open));
+            const uint32_t nT = (uint32_t)__popcll(__ballot(mine && open));
+            if (nW + nT == 0u) break;
+            if (nT == 0u || (nW != 0u && nT * 64u < A.t_test_frac * (nW + nT))) {
+#pragma unroll
+                for (int u = 0; u < RTM_FWALK_UNROLL; ++u) {
+                    if (st == TS_TRAV && model_i == mm && !open) {
+                        if (!fresh) RTF_DDA_ADVANCE();  // core.rs:151-167
+                        fresh = false;
+                        if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {  // core.rs:129-134
+                            if (STATS) cnt.v[C_CELLS]++;
+                            const uint32_t cell = ((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix;
+                            uint32_t word;
+                            if (occ_in_lds) word = occ_lds[occ_base + (cell >> 5)];
+                            else word = occ_glb[cell >> 5];
+                            if ((word >> (cell & 31u)) & 1u) {  // non-empty: the list is [k, k_end), k < k_end
+                                k = cell_start[cell];
+                                k_end = cell_start[cell + 1];
+                                open = true;
+                            }
+                        } else {  // left the grid without a hit
+                            model_i = mm + 1;
+                            if (last_model) finish_ray(); else st = TS_ENTER;
+                        }
+                    }
+                }
+            } else {
+                if (mine && open) {
+                    // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
+                    // reference's early returns become one predicate built from the same comparisons (so NaNs take
+                    // the same side).  Entries are applied in list order (core.rs:140-142).
+                    const uint32_t left = k_end - k;
+                    const uint32_t cntw = left < (uint32_t)RTM_FTRI_WIDE ? left : (uint32_t)RTM_FTRI_WIDE;
+                    uint32_t ti[RTM_FTRI_WIDE];
+                    double tt[RTM_FTRI_WIDE];
+                    bool ok[RTM_FTRI_WIDE];
+#pragma unroll
+                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) ti[j] = tri_idx[k + ((uint32_t)j < cntw ? (uint32_t)j : 0u)];
+#pragma unroll
+                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) {
+                        tt[j] = 0.0;
+                        ok[j] = false;
+                        // slots beyond the second are evaluated only when some lane of the wave has that many
+                        // entries left in its cell (wave-uniform branch: lists along a ray are mostly short)
+                        if (j >= 2 && !__ballot((uint32_t)j < cntw)) continue;
+                        const gptr<double> tp = tri_pos + (size_t)ti[j] * 9;
+                        const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
+                        const V3 pv = cross(d, e2);
+                        const double det = dot(e1, pv);
+                        const double inv = 1.0 / det;
+                        const V3 tv = o - v0;
+                        const double u = dot(tv, pv) * inv;
+                        const V3 qv = cross(tv, e1);
+                        const double v = dot(d, qv) * inv;
+                        tt[j] = dot(e2, qv) * inv;
+                        ok[j] = (uint32_t)j < cntw && !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) &&
+                                !(tt[j] < 0.0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) {
+                        const bool take = ok[j] && (!have || tt[j] < m_t);
+                        m_t = take ? tt[j] : m_t;
+                        m_tri = take ? ti[j] : m_tri;
+                        have = have || take;
+                    }
+                    if (STATS) cnt.v[C_TRI] += cntw;
+                    k += cntw;
+                    open = k < k_end;
+                }
+            }
+            const unsigned long long still = __ballot(st == TS_TRAV && model_i == mm);
+            if (!still) break;
+            if (!exhausted && (uint32_t)__popcll(__ballot(st == TS_IDLE)) >= A.refill) break;
+            if ((uint32_t)__popcll(still) < A.t_min_lanes && __ballot(st == TS_ENTER)) break;
+        }
+        // a hit accepted in the last iteration (the loop may leave before its next top)
+        if (st == TS_TRAV && model_i == mm && !open && have) {
+            if (STATS) cnt.v[C_MHIT]++;
+            model_result(true, mm, M_obj);
+            model_i = mm + 1;
+            if (last_model) finish_ray(); else st = TS_ENTER;
+        }
+    }
+#undef RTF_DDA_ADVANCE
+    flush_counters<STATS>(cnt, out_cnt);
+}
+
+// ================================================================================================
+// resolve: pixel = sum over samples, in sample order, of colour / n (main.rs:169)
+__global__ __launch_bounds__(kBlock) void front_resolve_kernel(FrontArgs A, double* __restrict__ out_rgb) {
+    const uint32_t pid = blockIdx.x * kBlock + threadIdx.x;
+    if (pid >= A.npix) return;
+    const uint32_t tile = pid >> 6, in = pid & 63u;
+    const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
+    const uint32_t lyc = (tile / A.tiles_x) * 8u + (in >> 3);
+    if (!(x < A.W && lyc < A.rows)) return;
+    const size_t np = A.np;
+    const double n_spp = (double)A.spp;
+    V3 px = mk(0, 0, 0);
+    for (uint32_t s = 0; s < A.spp; ++s) {
+        const size_t p = (size_t)s * A.npix + pid;
+        px = px + mk(A.D[(PF_COL + 0) * np + p], A.D[(PF_COL + 1) * np + p], A.D[(PF_COL + 2) * np + p]) / n_spp;
+    }
+    const size_t oi = (size_t)(A.row0 + lyc) * A.W + x;
+    out_rgb[oi * 3] = px.x;
+    out_rgb[oi * 3 + 1] = px.y;
+    out_rgb[oi * 3 + 2] = px.z;
+}
+
+}  // namespace rtf
