@@ -84,7 +84,10 @@ typedef struct rtm_scene {
 
 #define RTM_FLAG_ZERO_JITTER 1u /* x_offset = y_offset = 0 (known-answer tests); reference always jitters, main.rs:162-163 */
 
-#define RTM_FLAG_KERNEL_V1 2u   /* use the straight per-lane kernel (rt_device.h) instead of the wave-scheduled one; same results */
+/* Three device formulations of the same arithmetic exist; all give bit-identical images.  Default: the ray-front
+ * pipeline (rt_front.h).  The two flags select the older single-kernel forms (kept as cross-checks). */
+#define RTM_FLAG_KERNEL_V1 2u   /* the straight per-lane kernel (rt_device.h) */
+#define RTM_FLAG_KERNEL_WAVE 4u /* the wave-scheduled single kernel (rt_wave.h) */
 
 typedef struct rtm_params {
     uint32_t width, height;       /* ImageData.width/height (parser.rs:80-81) */
@@ -115,6 +118,13 @@ int rtm_shutdown(void);
 const char* rtm_last_error(void);
 /* Library version string and the gfx target it was compiled for. */
 const char* rtm_version(void);
+/* Scheduling knobs of the device path (no effect on results; no counterpart in the reference).  Keys:
+ *   "front_max_paths"  sample paths kept in flight per band of rows (workspace: ~700 B each; default 32 Mi),
+ *   "front_cull"       1 (default): shadow rays whose light is behind the surface (main.rs:96 fails) are not traced,
+ *   "front_refill"     idle lanes per wave at which the trace kernel fetches new rays (default 16).
+ * Returns RTM_ERR_INVALID for an unknown key or a value out of range.  The same knobs are read from the
+ * environment (RTM_FRONT_MAX_PATHS, ...) by rtm_init. */
+int rtm_set_tuning(const char* key, long long value);
 
 /* Replaces main.rs:153-171 verbatim: fills out_rgb[(k*width + x)*3 + c] (f64, linear, unclamped; for
  * row_begin=0,row_stride=1 that is pixels[x + width*y], main.rs:177).  Optional outputs (may be NULL):

@@ -28,6 +28,7 @@ INCLUDE_PATH = os.path.join(os.path.dirname(_HERE), "include", "rt_mi355x.h")
 NO_ID = 0xFFFFFFFF
 FLAG_ZERO_JITTER = 1
 FLAG_KERNEL_V1 = 2
+FLAG_KERNEL_WAVE = 4
 STAT_NAMES = ("rays_camera", "rays_bounce", "rays_shadow", "sphere_tests", "plane_tests", "bbox_tests",
               "cells_visited", "tri_tests", "model_hits")
 
@@ -108,7 +109,7 @@ _lib.rtm_frontend_size.argtypes = [_vp, _PU, _PU]
 _lib.rtm_frontend_free.argtypes = [_vp]
 
 EXPORTED_SYMBOLS = (
-    "rtm_local_rows", "rtm_init", "rtm_shutdown", "rtm_last_error", "rtm_version", "rtm_render", "rtm_scene_upload",
+    "rtm_local_rows", "rtm_init", "rtm_shutdown", "rtm_last_error", "rtm_version", "rtm_set_tuning", "rtm_render", "rtm_scene_upload",
     "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_trace_rays", "rtm_tonemap_device",
     "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
     "rtm_frontend_size", "rtm_frontend_free")
@@ -141,9 +142,15 @@ def init(device: int = -1):
     _inited = True
 
 
+def set_tuning(key: str, value: int):
+    """rtm_set_tuning: scheduling knobs of the device path (results never change)."""
+    _lib.rtm_set_tuning.argtypes = [C.c_char_p, C.c_longlong]
+    _check(_lib.rtm_set_tuning(key.encode(), int(value)))
+
+
 def make_params(width: int, height: int, spp: int = 1, seed: int = 0, max_bounces: int = 10, row_begin: int = 0,
-                row_stride: int = 1, zero_jitter: bool = False, kernel_v1: bool = False) -> RtmParams:
-    flags = (FLAG_ZERO_JITTER if zero_jitter else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0)
+                row_stride: int = 1, zero_jitter: bool = False, kernel_v1: bool = False, kernel_wave: bool = False) -> RtmParams:
+    flags = (FLAG_ZERO_JITTER if zero_jitter else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_WAVE if kernel_wave else 0)
     return RtmParams(width, height, spp, max_bounces, seed, row_begin, row_stride, flags, 0)
 
 
@@ -241,12 +248,12 @@ class Scene:
 
     def render(self, spp: int = 1, seed: int = 0, width: int = 0, height: int = 0, max_bounces: int = 10,
                row_begin: int = 0, row_stride: int = 1, zero_jitter: bool = False, ids: bool = True,
-               stats: bool = False, kernel_v1: bool = False) -> dict:
+               stats: bool = False, kernel_v1: bool = False, kernel_wave: bool = False) -> dict:
         """rtm_render: host buffers in, host buffers out (the drop-in for main.rs:153-171)."""
         if not _inited:
             init()
         p = make_params(width or self.width, height or self.height, spp, seed, max_bounces, row_begin, row_stride,
-                        zero_jitter, kernel_v1)
+                        zero_jitter, kernel_v1, kernel_wave)
         rows = local_rows(p)
         rgb = np.zeros((rows, p.width, 3))
         obj = np.zeros((rows, p.width), dtype=np.uint32) if ids else None

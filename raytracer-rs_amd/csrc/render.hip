@@ -11,7 +11,7 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_device.h"
-#include "rt_multi.h"
+#include "rt_wave.h"
 #include "rt_front.h"
 
 #pragma clang fp contract(off)
@@ -34,7 +34,7 @@ static int g_device = -1;
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
-static int g_kernel = 0;              // 0: rt_wave.h, 1: rt_multi.h, 2: rt_front.h; env RTM_KERNEL=wave|multi|front
+static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); env RTM_KERNEL=wave|front
 static uint32_t g_front_refill = 16, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
 struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
     char* base = nullptr;
@@ -271,15 +271,24 @@ int rtm_init(int device) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : (std::string(e) == "multi" ? 1 : 2);
+    if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : 2;
     if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
     if (const char* e = std::getenv("RTM_FRONT_CULL")) g_front_cull = std::atoi(e) ? 1u : 0u;
-    if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(4096ll, std::atoll(e));
+    if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(64ll, std::atoll(e));
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_TEST_FRAC")) g_t_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     return RTM_OK;
+}
+
+int rtm_set_tuning(const char* key, long long value) {
+    if (!key) return rtm_internal_fail(RTM_ERR_INVALID, "key is null");
+    const std::string k(key);
+    if (k == "front_max_paths" && value >= 64 && value <= (1ll << 31)) { g_front_max_paths = (size_t)value; return RTM_OK; }
+    if (k == "front_cull" && (value == 0 || value == 1)) { g_front_cull = (uint32_t)value; return RTM_OK; }
+    if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
+    return rtm_internal_fail(RTM_ERR_INVALID, "unknown tuning key or value out of range: " + k);
 }
 
 int rtm_shutdown(void) {
@@ -392,8 +401,10 @@ int rtm_scene_free(rtm_scene_dev* sd) {
 // ---- rt_front.h orchestration ---------------------------------------------------------------------
 namespace {
 
-bool front_supported(const rtm_scene_dev* sd) {
-    return sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide;
+bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
+    // packed cell coordinates and model indices (rt_front.h); one 8-row band of paths must fit the workspace budget
+    const uint64_t band_paths = (uint64_t)((p->width + 7) / 8) * 64u * p->spp;
+    return sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && band_paths <= (64ull << 20);
 }
 
 // One frame as bands of rows; per band: round 0 (camera rays), then shade/trace rounds until no path is alive.
@@ -490,13 +501,12 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         }
         AW.occ_words = words;
     }
-    const bool multi = g_kernel == 1;
-    const size_t wave_lds = (size_t)(multi ? rtq::kColdBytes : rtw::kColdBytes) + (size_t)AW.occ_words * 4;
+    const size_t wave_lds = (size_t)rtw::kColdBytes + (size_t)AW.occ_words * 4;
     // persistent grid: enough workgroups to fill every CU at the kernel's occupancy; each wave claims 8x8 tiles
     static const uint32_t wgs_env = std::getenv("RTM_WGS_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("RTM_WGS_PER_CU"))) : 0u;
-    const uint32_t wgs_per_cu = wgs_env ? wgs_env : (multi ? (uint32_t)RTM_MULTI_OCC : (uint32_t)RTM_WAVE_OCC);
+    const uint32_t wgs_per_cu = wgs_env ? wgs_env : (uint32_t)RTM_WAVE_OCC;
     const uint32_t wave_wgs = std::min<uint32_t>((AW.n_tiles + 3) / 4, (uint32_t)g_num_cus * wgs_per_cu);
-    const bool front = !v1 && g_kernel == 2 && front_supported(sd);
+    const bool front = !v1 && !(p->flags & RTM_FLAG_KERNEL_WAVE) && g_kernel == 2 && front_supported(sd, p);
     int front_rc = RTM_OK;
     auto launch = [&](bool stats, unsigned long long* d_cnt) {
         if (front) {
@@ -509,13 +519,8 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         } else {
             hipError_t me = hipMemsetAsync(g_work_counter, 0, 256, stream);  // claimed tiles start at 0 every frame
             if (me != hipSuccess) return me;
-            if (multi) {
-                if (stats) hipLaunchKernelGGL(rtq::render_multi_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-                else hipLaunchKernelGGL(rtq::render_multi_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-            } else {
-                if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-                else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-            }
+            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
         }
         return hipGetLastError();
     };
@@ -530,14 +535,18 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         (void)hipFree(d_cnt);
         if (front_rc != RTM_OK) return front_rc;
         if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
-        if (std::getenv("RTM_DIAG") && h[9])
+        if (std::getenv("RTM_DIAG") && front)
+            std::fprintf(stderr, "[rtm diag front] test steps %llu (avg %.1f lanes)  walk iters %llu (avg %.1f lanes)  test slots %llu (avg %.1f lanes)  refills %llu (avg %.1f lanes)\n",
+                         h[9], h[9] ? (double)h[10] / (double)h[9] : 0.0, h[11], h[11] ? (double)h[12] / (double)h[11] : 0.0, h[13],
+                         h[13] ? (double)h[14] / (double)h[13] : 0.0, h[15], h[15] ? (double)h[16] / (double)h[15] : 0.0);
+        if (std::getenv("RTM_DIAG") && !front && h[9])
             std::fprintf(stderr, "[rtm diag] S rounds %llu (avg %.1f lanes, %.0f cyc/round)  T steps %llu (avg %.1f lanes, %.0f cyc/step)  wave cycles: S %.1f%% T %.1f%% of %.3g\n",
                          h[9], (double)h[10] / (double)h[9], (double)h[13] / (double)h[9], h[11], h[11] ? (double)h[12] / (double)h[11] : 0.0,
                          h[11] ? (double)h[14] / (double)h[11] : 0.0, 100.0 * (double)h[13] / (double)h[15], 100.0 * (double)h[14] / (double)h[15], (double)h[15]);
-        if (std::getenv("RTM_DIAG") && h[9])
+        if (std::getenv("RTM_DIAG") && !front && h[9])
             std::fprintf(stderr, "[rtm diag] walks %llu wave-steps, %llu wave-iters (avg %.1f lanes); test slots %llu (avg %.1f lanes); bbox %llu cells %llu tri %llu mhit %llu\n",
                          h[20], h[16], h[16] ? (double)h[17] / (double)h[16] : 0.0, h[18], h[18] ? (double)h[19] / (double)h[18] : 0.0, h[5], h[6], h[7], h[8]);
-        if (std::getenv("RTM_DIAG") && h[9] && h[24])
+        if (std::getenv("RTM_DIAG") && !front && h[9] && h[24])
             std::fprintf(stderr, "[rtm diag] S sub-blocks (cyc/round): decide+rng %.0f  normal %.0f  shadow+finish+sample %.0f  next-ray %.0f  analytic %.0f  enter %.0f\n",
                          (double)h[24] / (double)h[9], (double)h[25] / (double)h[9], (double)h[26] / (double)h[9], (double)h[27] / (double)h[9],
                          (double)h[28] / (double)h[9], (double)h[29] / (double)h[9]);

@@ -513,6 +513,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     double bt = 0.0;  // closest model hit of this ray so far, over the models visited (core.rs:79-83)
     uint32_t bm = kNoId, btri = kNoId, bobj = kNoId;
     bool exhausted = sq >= A.nq;
+    uint64_t dg_steps = 0, dg_step_lanes = 0, dg_walks = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_refills = 0, dg_refill_lanes = 0;  // STATS only, wave-uniform
 
     auto finish_ray = [&]() __attribute__((always_inline)) {
         A.res_t[q] = bt;
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         unsigned long long busy = __ballot(st != TS_IDLE);
         // ---- refill: idle lanes take the next items of the wave's block, in order
         if (!exhausted && ((uint32_t)__popcll(idle) >= A.refill || !busy)) {
+            if (STATS) { dg_refills++; dg_refill_lanes += (uint64_t)__popcll(idle); }
             for (;;) {
                 idle = __ballot(st == TS_IDLE);
                 if (!idle) break;
@@ -651,6 +653,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             const uint32_t nT = (uint32_t)__popcll(__ballot(mine && open));
             if (nW + nT == 0u) break;
             if (nT == 0u || (nW != 0u && nT * 64u < A.t_test_frac * (nW + nT))) {
+                if (STATS) { dg_walks++; dg_walk_lanes += nW; }
 #pragma unroll
                 for (int u = 0; u < RTM_FWALK_UNROLL; ++u) {
                     if (st == TS_TRAV && model_i == mm && !open) {
@@ -674,6 +677,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     }
                 }
             } else {
+                if (STATS) { dg_steps++; dg_step_lanes += nT; }
                 if (mine && open) {
                     // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
@@ -691,7 +695,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         ok[j] = false;
                         // slots beyond the second are evaluated only when some lane of the wave has that many
                         // entries left in its cell (wave-uniform branch: lists along a ray are mostly short)
-                        if (j >= 2 && !__ballot((uint32_t)j < cntw)) continue;
+                        const unsigned long long wants = __ballot((uint32_t)j < cntw);
+                        if (j >= 2 && !wants) continue;
+                        if (STATS) { dg_slots++; dg_slot_lanes += (uint64_t)__popcll(wants); }
                         const gptr<double> tp = tri_pos + (size_t)ti[j] * 9;
                         const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
                         const V3 pv = cross(d, e2);
@@ -732,6 +738,11 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     }
 #undef RTF_DDA_ADVANCE
     flush_counters<STATS>(cnt, out_cnt);
+    if (STATS && lane == 0) {
+        const uint64_t dv[8] = {dg_steps, dg_step_lanes, dg_walks, dg_walk_lanes, dg_slots, dg_slot_lanes, dg_refills, dg_refill_lanes};
+        for (int i = 0; i < 8; ++i)
+            if (dv[i]) atomicAdd(out_cnt + 9 + i, (unsigned long long)dv[i]);
+    }
 }
 
 // ================================================================================================

@@ -56,12 +56,16 @@ def test_f64_primitives_are_ieee(rtm_gpu):
         assert same.all(), f"{name}: {int((~same).sum())} of {n} differ, e.g. a={a[~same][0]!r} b={b[~same][0]!r}"
 
 
-@pytest.mark.parametrize("kernel_v1", (False, True), ids=("wave", "v1"))
+KERNELS = {"front": {}, "wave": dict(kernel_wave=True), "v1": dict(kernel_v1=True)}
+
+
+@pytest.mark.parametrize("kernel", tuple(KERNELS))
 @pytest.mark.parametrize("name", SCENES)
-def test_full_size_1spp_matches_oracle(name, kernel_v1, rtm_gpu, rtm_scene, oracle_scene):
-    """BASELINE configs 1-4 at the reference's own 1200x1200, 1 spp, same seed; both kernels (the wave-scheduled
-    production kernel and the straight per-lane one) must give the oracle's bits."""
-    g = rtm_scene(name).render(spp=1, seed=11, stats=True, kernel_v1=kernel_v1)
+def test_full_size_1spp_matches_oracle(name, kernel, rtm_gpu, rtm_scene, oracle_scene):
+    """BASELINE configs 1-4 at the reference's own 1200x1200, 1 spp, same seed; all three device formulations (the
+    ray-front pipeline that is the product path, the wave-scheduled single kernel and the straight per-lane kernel)
+    must give the oracle's bits and its exact work counters."""
+    g = rtm_scene(name).render(spp=1, seed=11, stats=True, **KERNELS[kernel])
     c = oracle_scene(name).render(spp=1, seed=11)
     assert g["rgb"].shape == (1200, 1200, 3)
     assert_frames_match(g, c, name)
@@ -89,6 +93,37 @@ def test_n_spp_psnr(name, rtm_gpu, rtm_scene, oracle_scene):
     c = oracle_scene(name).render(spp=20, seed=5, width=200, height=200)
     assert psnr(g["rgb"], c["rgb"]) >= PSNR_MIN_DB
     assert_frames_match(g, c, name + " 20spp")
+
+
+@pytest.mark.parametrize("kernel", tuple(KERNELS))
+def test_kernels_agree_at_n_spp(kernel, rtm_gpu, rtm_scene, oracle_scene):
+    """8 spp, 10 bounces, without the stats build (the ray-front path then skips shadow rays that cannot contribute):
+    every formulation gives the oracle's bits."""
+    c = oracle_scene("bunny").render(spp=8, seed=21, width=160, height=120)
+    g = rtm_scene("bunny").render(spp=8, seed=21, width=160, height=120, **KERNELS[kernel])
+    assert_frames_match(g, c, "bunny 8spp " + kernel)
+
+
+def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, oracle_scene):
+    """The ray-front scheduling knobs (rtm_set_tuning): many small bands of rows, ragged last band, culling off,
+    eager and lazy refill -- same image, ids and counters."""
+    s = rtm_scene("suzanne")
+    ref = oracle_scene("suzanne").render(spp=3, seed=4, width=203, height=77)
+    try:
+        for key, value in (("front_max_paths", 64), ("front_max_paths", 26 * 64 * 3 * 4), ("front_cull", 0), ("front_refill", 1),
+                           ("front_refill", 64)):
+            rtm_gpu.set_tuning(key, value)
+            g = s.render(spp=3, seed=4, width=203, height=77, stats=True)
+            assert_frames_match(g, ref, f"suzanne {key}={value}")
+            assert g["counters"] == ref["counters"]
+            g = s.render(spp=3, seed=4, width=203, height=77)
+            assert np.array_equal(g["rgb"], ref["rgb"])
+    finally:
+        rtm_gpu.set_tuning("front_max_paths", 32 << 20)
+        rtm_gpu.set_tuning("front_cull", 1)
+        rtm_gpu.set_tuning("front_refill", 16)
+    with pytest.raises(rtm_gpu.RtmError):
+        rtm_gpu.set_tuning("no_such_knob", 1)
 
 
 def test_zero_jitter_known_answer(rtm_gpu, rtm_scene):
@@ -151,11 +186,17 @@ def test_edge_cases(rtm_gpu, orc):
                     ("size 40 40\nsphere (0,0,3) 1 metal:white\nplane (0,1,0) 1 white\nlight (2,-3,0) orange",
                      dict(max_bounces=1)),
                     ("size 40 40\nsphere (0,0,3) 1 metal:white\nplane (0,1,0) 1 white\nlight (2,-3,0) orange",
-                     dict(max_bounces=64, spp=3))):
-        g = rtm_gpu.Scene(text=txt).render(seed=4, stats=True, **kw)
+                     dict(max_bounces=64, spp=3)),
+                    ("size 48 40\nsphere (0,0,4) 1 white\nsphere (1.5,0.5,3) 0.5 metal:cyan\nplane (0,1,0) 1 white\n"
+                     "light (2,-3,0) orange\nlight (-2,-3,1) white\nlight (0,-4,4) red\nlight (3,-1,6) green\nlight (0,2,2) blue",
+                     dict(spp=2, max_bounces=5))):                              # five lights: three batches of shadow rays
         c = orc.OracleScene(text=txt).render(seed=4, **kw)
-        assert_frames_match(g, c, txt.splitlines()[0])
-        assert g["counters"] == c["counters"]
+        for kernel, sel in KERNELS.items():
+            g = rtm_gpu.Scene(text=txt).render(seed=4, stats=True, **kw, **sel)
+            assert_frames_match(g, c, txt.splitlines()[0] + " " + kernel)
+            assert g["counters"] == c["counters"]
+            g = rtm_gpu.Scene(text=txt).render(seed=4, **kw, **sel)  # (no counters: the ray-front path culls)
+            assert np.array_equal(g["rgb"], c["rgb"])
     sky = rtm_gpu.Scene(text="size 20 13").render()
     assert (sky["rgb"] == 1.0).all() and (sky["obj_id"] == rtm_gpu.NO_ID).all()
 
@@ -222,6 +263,8 @@ def test_differential_fuzz_random_scenes(rtm_gpu, orc):
         cr = b.render(spp=2, seed=trial)
         assert_frames_match(gr, cr, f"fuzz scene {trial}")
         assert gr["counters"] == cr["counters"]
+        assert np.array_equal(a.render(spp=2, seed=trial)["rgb"], cr["rgb"])                    # culling on
+        assert np.array_equal(a.render(spp=2, seed=trial, kernel_wave=True)["rgb"], cr["rgb"])
 
 
 def test_teapot_and_soup_scene(rtm_gpu, orc):
