@@ -41,20 +41,17 @@ enum : int {
     PF_O = 4,      // origin shared by the path's queries: the camera or the vertex being shaded
     PF_D0 = 7,     // direction of the camera / bounce query
     PF_BA0 = 10,   // its closest analytic hit (spheres, planes)
-    PF_SD = 11,    // directions of the two shadow queries
-    PF_SBA = 17,   // their closest analytic hits
-    PF_SDL2 = 19,  // squared distances to their lights
-    PF_SC = 21,    // what each adds to the diffuse sum if it is not occluded (main.rs:96-102)
-    PF_DIFF = 27,  // diffuse sum so far (scenes with more than two lights)
-    PF_NRM = 30,   // shading normal (scenes with more than two lights)
-    PF_COUNT = 33
+    PF_SBA = 11,   // closest analytic hits of the two shadow queries
+    PF_NRM = 13,   // shading normal of the vertex being shaded
+    PF_DIFF = 16,  // diffuse sum so far (scenes with more than two lights)
+    PF_COUNT = 19
 };
 enum : int { PU_FL = 0, PU_CTR = 1, PU_HOBJ = 2, PU_HMAT = 3, PU_HKP = 4, PU_MAT = 5, PU_COUNT = 6 };
 enum : uint32_t {
     FB_HASV = 1u,                              // a shaded vertex waits for its shadow results
     FB_FOUND0 = 2u, FB_FOUND1 = 4u, FB_FOUND2 = 8u,  // query j has an analytic hit
     FB_TQ0 = 16u, FB_TQ1 = 32u, FB_TQ2 = 64u,        // query j went to the trace kernel: res_*[3p+j] holds its model hit
-    FB_C1 = 128u, FB_C2 = 256u,                      // shadow query j faces its light (eff > 0.001): PF_SC is valid
+    FB_C1 = 128u, FB_C2 = 256u,                      // shadow query j faces its light (eff > 0.001, main.rs:96)
     FB_NSH_SHIFT = 9u                                // two bits: shadow queries in flight (0..2)
 };
 // trace items, structure of arrays over the item index
@@ -191,11 +188,22 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                 cont = true;
                 if (STATS) cnt.v[C_CAM]++;
             } else {
+                // ---- every load this round can need, issued before anything is decided: the kernel moves ~1 KB per
+                //      path and is bound by memory latency, not by the few bytes a path in another state would skip
                 fl = ldU(PU_FL);
                 const uint32_t ctr = ldU(PU_CTR);
+                const uint32_t q = p * 3u;
+                o = ldD3(PF_O);
+                const double l_ba0 = ldD(PF_BA0);
+                const uint32_t l_hobj = ldU(PU_HOBJ), l_hmat = ldU(PU_HMAT), l_hkp = ldU(PU_HKP), l_mat = ldU(PU_MAT);
+                const uint32_t l_rm0 = A.res_m[q], l_rm1 = A.res_m[q + 1u], l_rm2 = A.res_m[q + 2u];
+                const double l_rt0 = A.res_t[q], l_rt1 = A.res_t[q + 1u], l_rt2 = A.res_t[q + 2u];
+                const uint32_t l_rtri0 = A.res_tri[q];
+                const double l_sba0 = ldD(PF_SBA), l_sba1 = ldD(PF_SBA + 1);
+                const V3 l_nrm = ldD3(PF_NRM), l_d0 = ldD3(PF_D0), l_col = ldD3(PF_COL);
+                const double l_att = ldD(PF_ATT);
                 bounce = ctr & 0xFFFFu;
                 li = ctr >> 16;
-                o = ldD3(PF_O);
                 // ---- 0. decisions
                 const bool a_v = (fl & FB_HASV) != 0u;
                 const uint32_t n_in = a_v ? ((fl >> FB_NSH_SHIFT) & 3u) : 0u;  // shadow results to consume
@@ -203,27 +211,24 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                 const bool a_fin = a_v && !a_more;                              // the vertex is complete (main.rs:107-125)
                 const bool a_end = a_fin && (int)bounce + 1 >= K;               // ... and it was the last one allowed
                 const bool b_take = !a_more && !a_end;                          // the path query's result is due
-                const uint32_t q = p * 3u;
                 // ---- 1. the path query: analytic hit, then the model hit the trace kernel found (core.rs:75-83)
                 if (b_take) {
-                    best0 = ldD(PF_BA0);
+                    best0 = l_ba0;
                     found0 = (fl & FB_FOUND0) != 0u;
-                    h_obj = ldU(PU_HOBJ); h_mat = ldU(PU_HMAT); h_kp = ldU(PU_HKP);
-                    if (fl & FB_TQ0) {
-                        const uint32_t m = A.res_m[q];
-                        if (m != kNoId) {
-                            const double t = A.res_t[q];
-                            const uint32_t mobj = S.models[m].obj;
-                            if (!(t <= kEps) && (t < best0 || (found0 && t == best0 && mobj < h_obj))) {
-                                best0 = t; found0 = true;
-                                h_obj = mobj; h_mat = S.models[m].mat; h_kp = (2u << 30) | m; h_tri = A.res_tri[q];
-                            }
+                    h_obj = l_hobj; h_mat = l_hmat; h_kp = l_hkp;
+                    if ((fl & FB_TQ0) && l_rm0 != kNoId) {
+                        const uint32_t m = l_rm0;
+                        const double t = l_rt0;
+                        const uint32_t mobj = S.models[m].obj;
+                        if (!(t <= kEps) && (t < best0 || (found0 && t == best0 && mobj < h_obj))) {
+                            best0 = t; found0 = true;
+                            h_obj = mobj; h_mat = S.models[m].mat; h_kp = (2u << 30) | m; h_tri = l_rtri0;
                         }
                     }
                 }
                 const bool b_hit = b_take && found0, b_miss = b_take && !found0;
                 const bool end_sample = a_end || b_miss;
-                const uint32_t mat_old = a_fin ? ldU(PU_MAT) : 0u;
+                const uint32_t mat_old = a_fin ? l_mat : 0u;
                 const bool metal_old = S.materials[(size_t)mat_old * 4 + 3] != 0.0;
                 const uint32_t mat_new = b_hit ? h_mat : mat_old;
                 const bool metal_new = S.materials[(size_t)mat_new * 4 + 3] != 0.0;
@@ -234,33 +239,40 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                     philox(A.seed, pixel, s, 1u + 2u * bounce_new, ra);
                     philox(A.seed, pixel, s, 2u + 2u * bounce_new, rb);
                 }
-                // ---- 2. shadow results of the pending vertex, in light order (main.rs:86-104); o == P
+                // ---- 2. shadow results of the pending vertex, in light order (main.rs:80-104); o == P.  The ray towards
+                //      the light and what it would add are recomputed from (P, n, light) -- the same expressions that
+                //      produced the ray -- rather than carried through memory.
                 V3 diff = mk(0, 0, 0);
                 if (n_in > 0u) {
                     if (li > 0u) diff = ldD3(PF_DIFF);
-                    auto shade = [&](const uint32_t j) __attribute__((always_inline)) {
+                    auto shade = [&](const uint32_t j, const double sba, const uint32_t rm, const double rt) __attribute__((always_inline)) {
                         if (j < n_in && (fl & (FB_C1 << j))) {  // a query that cannot contribute is not looked at
-                            double best = ldD(PF_SBA + (int)j);
+                            const double* L = S.lights + (size_t)(li + j) * 8;
+                            const V3 lp = ld3(L);
+                            const V3 dir = normalize(lp - o);
+                            const double dl2 = sqdist(o, lp);
+                            double best = sba;
                             bool found = (fl & (FB_FOUND1 << j)) != 0u;
-                            if (fl & (FB_TQ1 << j)) {
-                                const uint32_t m = A.res_m[q + 1u + j];
-                                const double t = A.res_t[q + 1u + j];
-                                if (m != kNoId && !(t <= kEps) && t < best) { best = t; found = true; }
-                            }
+                            if ((fl & (FB_TQ1 << j)) && rm != kNoId && !(rt <= kEps) && rt < best) { best = rt; found = true; }
                             bool occluded = false;
-                            if (found) occluded = sqdist(ray_at(o, ldD3(PF_SD + 3 * (int)j), best), o) <= ldD(PF_SDL2 + (int)j);
-                            if (!occluded) diff = diff + ldD3(PF_SC + 3 * (int)j);
+                            if (found) occluded = sqdist(ray_at(o, dir, best), o) <= dl2;
+                            if (!occluded) {
+                                const double eff = dot(dir, l_nrm);  // > 0.001, or FB_C would not be set
+                                const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
+                                const double decay = 1.0 / dd;
+                                diff = diff + ld3(L + 3) * decay * eff;
+                            }
                         }
                     };
-                    shade(0u);
-                    shade(1u);
+                    shade(0u, l_sba0, l_rm1, l_rt1);
+                    shade(1u, l_sba1, l_rm2, l_rt2);
                     li += n_in;
                     if (a_more) stD3(PF_DIFF, diff);
                 }
                 // ---- 3. end of the light loop: the surface's colour, attenuation (main.rs:107-125)
                 V3 col = mk(0, 0, 0);
                 double att = 0.0;
-                if (a_fin || b_miss) { col = ldD3(PF_COL); att = ldD(PF_ATT); }
+                if (a_fin || b_miss) { col = l_col; att = l_att; }
                 if (a_fin) {
                     const double* mp = S.materials + (size_t)mat_old * 4;
                     col = col + ld3(mp) * att * (diff * (metal_old ? 0.2 : 0.9));
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                 bool norm0 = false;
                 if (b_hit) {
                     // surface point and shading normal (core.rs:89,169-177,195,209; main.rs:68-73)
-                    const V3 d = ldD3(PF_D0);
+                    const V3 d = l_d0;
                     const V3 P = ray_at(o, d, best0);
                     const uint32_t kind = h_kp >> 30, prim = h_kp & 0x3FFFFFFFu;
                     V3 raw;
@@ -300,11 +312,11 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                     stU(PU_MAT, mat_new);
                     o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
                     stD3(PF_O, o);
-                    if (nL > 2u) stD3(PF_NRM, nn);
+                    stD3(PF_NRM, nn);
                     li = 0;
                     fl |= FB_HASV;
                 } else if (a_more) {
-                    nn = ldD3(PF_NRM);
+                    nn = l_nrm;
                 }
                 // ---- 5. the new queries
                 go0 = b_hit && (int)bounce + 1 < K;
@@ -370,7 +382,6 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                     stD(PF_BA0, best);
                     stU(PU_HOBJ, b_obj); stU(PU_HMAT, b_mat); stU(PU_HKP, b_kp);
                 } else {
-                    stD3(PF_SD + 3 * ((int)j - 1), dir);
                     stD(PF_SBA + (int)j - 1, best);
                 }
                 if (found) fl |= FB_FOUND0 << j;
@@ -434,16 +445,9 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                     const double* L = S.lights + (size_t)(li + j) * 8;
                     const V3 lp = ld3(L);
                     dir = normalize(lp - o);
-                    const double dl2 = sqdist(o, lp);
-                    stD(PF_SDL2 + (int)j, dl2);
                     const double eff = dot(dir, nn);
-                    const bool lit = eff > 0.001;
-                    if (lit) {
-                        const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
-                        const double decay = 1.0 / dd;
-                        stD3(PF_SC + 3 * (int)j, ld3(L + 3) * decay * eff);
-                        fl |= FB_C1 << j;
-                    }
+                    const bool lit = eff > 0.001;  // main.rs:96: otherwise the query's answer is never used
+                    if (lit) fl |= FB_C1 << j;
                     trace = lit || !A.cull;
                 }
                 issue(1u + j, go && trace, dir);  // (the host turns culling off when exact work counters are wanted)
