@@ -382,6 +382,16 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
                 pos[(size_t)t * 9 + a] = a < 3 ? M.pos[a][t] : M.pos[a][t] - M.pos[a % 3][t];
                 nrm[(size_t)t * 9 + a] = M.nrm[a][t];
             }
+        // the lists again, as records in list order (rt_front.h): a cell's entries are contiguous 80-byte records, so the
+        // traversal reads them without the indirection through tri_idx and neighbouring entries share cache lines
+        std::vector<double> rec((size_t)M.n_tri_idx * 10);
+        for (uint64_t e = 0; e < M.n_tri_idx; ++e) {
+            const uint32_t t = idx[e];
+            for (int a = 0; a < 9; ++a) rec[e * 10 + a] = pos[(size_t)t * 9 + a];
+            const uint64_t bits = t;
+            std::memcpy(&rec[e * 10 + 9], &bits, 8);
+        }
+        if ((rc = upload(sd, rec, &D.cell_rec))) return fail(rc);
         if ((rc = upload(sd, start, &D.cell_start)) || (rc = upload(sd, idx, &D.tri_idx)) || (rc = upload(sd, pos, &D.tri_pos)) ||
             (rc = upload(sd, nrm, &D.tri_nrm)) || (rc = upload(sd, occ, &D.occupancy)))
             return fail(rc);
@@ -444,6 +454,9 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const dim3 block(256);
     const uint32_t shade_wgs = nq / 4u;
     const uint32_t trace_wgs = (uint32_t)g_num_cus * (uint32_t)RTM_FRONT_OCC;
+    uint32_t occ_total = 0;
+    for (uint32_t w : sd->occ_words) occ_total += w;
+    const bool all_lds = occ_total == occ_words;  // every bitmap is staged in LDS
     for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk) {
         const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
         rtf::FrontArgs A{};
@@ -469,8 +482,14 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
             }
             if (r + 1 < rounds) {  // the last round only finalises
-                if (stats) hipLaunchKernelGGL(rtf::front_trace_kernel<true>, dim3(trace_wgs), block, (size_t)occ_words * 4, stream, sd->view, A, d_cnt);
-                else hipLaunchKernelGGL(rtf::front_trace_kernel<false>, dim3(trace_wgs), block, (size_t)occ_words * 4, stream, sd->view, A, d_cnt);
+                const size_t lds = (size_t)occ_words * 4;
+                if (stats) {
+                    if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<true, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
+                    else hipLaunchKernelGGL((rtf::front_trace_kernel<true, false>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
+                } else {
+                    if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<false, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
+                    else hipLaunchKernelGGL((rtf::front_trace_kernel<false, false>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
+                }
             }
             HIP_TRY(hipGetLastError());
         }
@@ -535,6 +554,10 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         (void)hipFree(d_cnt);
         if (front_rc != RTM_OK) return front_rc;
         if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
+        if (std::getenv("RTM_DIAG") && front && h[22])
+            std::fprintf(stderr, "[rtm diag front] trace waves %llu: mean %.0f cycles, sum of per-launch max not tracked; max single wave %llu cycles; total wave-cycles %.3g: refill %.1f%% (%.0f/refill)  walk %.1f%% (%.0f/iter)  test %.1f%% (%.0f/step)\n",
+                         h[22], (double)h[20] / (double)h[22], h[21], (double)h[20], 100.0 * h[23] / (double)h[20], h[15] ? (double)h[23] / h[15] : 0.0,
+                         100.0 * h[24] / (double)h[20], h[11] ? (double)h[24] / h[11] : 0.0, 100.0 * h[25] / (double)h[20], h[9] ? (double)h[25] / h[9] : 0.0);
         if (std::getenv("RTM_DIAG") && front)
             std::fprintf(stderr, "[rtm diag front] test steps %llu (avg %.1f lanes)  walk iters %llu (avg %.1f lanes)  test slots %llu (avg %.1f lanes)  refills %llu (avg %.1f lanes)\n",
                          h[9], h[9] ? (double)h[10] / (double)h[9] : 0.0, h[11], h[11] ? (double)h[12] / (double)h[11] : 0.0, h[13],

@@ -15,6 +15,8 @@
 // attenuation, samples in order); only the order in which rays are traced changes, and every query is a pure
 // function of its ray.  The arithmetic of each block is the op sequence of rt_device.h: bit-identical results.
 #pragma once
+#include <type_traits>
+
 #include "rt_device.h"
 
 #pragma clang fp contract(off)
@@ -476,7 +478,8 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
 // trace: persistent lanes; a lane holds one ray and only ever walks cells or tests triangles
 enum : uint32_t { TS_IDLE = 0, TS_ENTER = 1, TS_TRAV = 2 };
 
-template <bool STATS>
+// ALL_LDS: every model's occupancy bitmap fits the LDS budget (the host checks)
+template <bool STATS, bool ALL_LDS>
 __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmDevScene S, FrontArgs A, unsigned long long* __restrict__ out_cnt) {
     extern __shared__ uint32_t occ_lds[];  // [A.occ_words]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -495,6 +498,8 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     Counters cnt;
     if (STATS)
         for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
+    const uint64_t dg_begin = STATS ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t dg_tr = 0, dg_tw = 0, dg_tt = 0, dg_t0 = 0;  // cycles in refill / walk / test (STATS)
     const size_t cap = A.cap_items;
     // the wave's position in the queue: it owns sub-queues sq, sq + waves, sq + 2 waves, ... and reads each in order
     const uint32_t trace_waves = gridDim.x * (kBlock / 64);
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         unsigned long long busy = __ballot(st != TS_IDLE);
         // ---- refill: idle lanes take the next items of the wave's block, in order
         if (!exhausted && ((uint32_t)__popcll(idle) >= A.refill || !busy)) {
-            if (STATS) { dg_refills++; dg_refill_lanes += (uint64_t)__popcll(idle); }
+            if (STATS) { dg_refills++; dg_refill_lanes += (uint64_t)__popcll(idle); dg_t0 = __builtin_amdgcn_s_memtime(); }
             for (;;) {
                 idle = __ballot(st == TS_IDLE);
                 if (!idle) break;
@@ -582,6 +587,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 pool_next += want < avail ? want : avail;
             }
             busy = __ballot(st != TS_IDLE);
+            if (STATS) dg_tr += __builtin_amdgcn_s_memtime() - dg_t0;
         }
         if (!busy) {
             if (exhausted) break;
@@ -636,9 +642,10 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             if (j < mm) occ_base += words;
         }
         const RtmDevModel& M = S.models[mm];
-        const uint32_t n = M.n, M_obj = M.obj;
-        const gptr<uint32_t> cell_start = as_global(M.cell_start), tri_idx = as_global(M.tri_idx);
-        const gptr<double> tri_pos = as_global(M.tri_pos);
+        // (wave-uniform by construction; said explicitly so that they live in SGPRs and cost no waits in the loop)
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.n), M_obj = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.obj);
+        const gptr<uint32_t> cell_start = as_global(M.cell_start);
+        const gptr<double> cell_rec = as_global(M.cell_rec);
         const gptr<uint32_t> occ_glb = as_global(M.occupancy);
         const bool occ_in_lds = occ_base != 0xFFFFFFFFu;
         const bool last_model = mm + 1u >= S.n_models;
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             const uint32_t nT = (uint32_t)__popcll(__ballot(mine && open));
             if (nW + nT == 0u) break;
             if (nT == 0u || (nW != 0u && nT * 64u < A.t_test_frac * (nW + nT))) {
-                if (STATS) { dg_walks++; dg_walk_lanes += nW; }
+                if (STATS) { dg_walks++; dg_walk_lanes += nW; dg_t0 = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
                 for (int u = 0; u < RTM_FWALK_UNROLL; ++u) {
                     if (st == TS_TRAV && model_i == mm && !open) {
@@ -667,7 +674,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                             if (STATS) cnt.v[C_CELLS]++;
                             const uint32_t cell = ((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix;
                             uint32_t word;
-                            if (occ_in_lds) word = occ_lds[occ_base + (cell >> 5)];
+                            // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one
+                            // block, the wait before the bit test would also wait for the previous step's cell_start loads)
+                            if (ALL_LDS || occ_in_lds) word = occ_lds[occ_base + (cell >> 5)];
                             else word = occ_glb[cell >> 5];
                             if ((word >> (cell & 31u)) & 1u) {  // non-empty: the list is [k, k_end), k < k_end
                                 k = cell_start[cell];
@@ -680,8 +689,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         }
                     }
                 }
+                if (STATS) dg_tw += __builtin_amdgcn_s_memtime() - dg_t0;
             } else {
-                if (STATS) { dg_steps++; dg_step_lanes += nT; }
+                if (STATS) { dg_steps++; dg_step_lanes += nT; dg_t0 = __builtin_amdgcn_s_memtime(); }
                 if (mine && open) {
                     // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     double tt[RTM_FTRI_WIDE];
                     bool ok[RTM_FTRI_WIDE];
 #pragma unroll
-                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) ti[j] = tri_idx[k + ((uint32_t)j < cntw ? (uint32_t)j : 0u)];
+                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) ti[j] = k + ((uint32_t)j < cntw ? (uint32_t)j : 0u);  // list positions
 #pragma unroll
                     for (int j = 0; j < RTM_FTRI_WIDE; ++j) {
                         tt[j] = 0.0;
@@ -702,8 +712,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         const unsigned long long wants = __ballot((uint32_t)j < cntw);
                         if (j >= 2 && !wants) continue;
                         if (STATS) { dg_slots++; dg_slot_lanes += (uint64_t)__popcll(wants); }
-                        const gptr<double> tp = tri_pos + (size_t)ti[j] * 9;
+                        const gptr<double> tp = cell_rec + (size_t)ti[j] * 10;
                         const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
+                        ti[j] = (uint32_t)__double_as_longlong(tp[9]);  // the record ends with the triangle's index
                         const V3 pv = cross(d, e2);
                         const double det = dot(e1, pv);
                         const double inv = 1.0 / det;
@@ -726,6 +737,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     k += cntw;
                     open = k < k_end;
                 }
+                if (STATS) dg_tt += __builtin_amdgcn_s_memtime() - dg_t0;
             }
             const unsigned long long still = __ballot(st == TS_TRAV && model_i == mm);
             if (!still) break;
@@ -741,6 +753,15 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         }
     }
 #undef RTF_DDA_ADVANCE
+    if (STATS && lane == 0) {
+        const unsigned long long el = (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_begin);
+        atomicAdd(out_cnt + 20, el);
+        atomicMax(out_cnt + 21, el);
+        atomicAdd(out_cnt + 22, 1ull);
+        atomicAdd(out_cnt + 23, (unsigned long long)dg_tr);
+        atomicAdd(out_cnt + 24, (unsigned long long)dg_tw);
+        atomicAdd(out_cnt + 25, (unsigned long long)dg_tt);
+    }
     flush_counters<STATS>(cnt, out_cnt);
     if (STATS && lane == 0) {
         const uint64_t dv[8] = {dg_steps, dg_step_lanes, dg_walks, dg_walk_lanes, dg_slots, dg_slot_lanes, dg_refills, dg_refill_lanes};

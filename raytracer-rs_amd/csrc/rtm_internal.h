@@ -25,6 +25,7 @@ struct RtmDevModel {
     const double* tri_pos;       // n_tris x 9: v0 xyz, (v1-v0) xyz, (v2-v0) xyz  -- edges of model.rs:46-47 / :20-21
     const double* tri_nrm;       // n_tris x 9
     const uint32_t* occupancy;   // n^3 bits: cell non-empty
+    const double* cell_rec;      // n_tri_idx x 10, in list order: the tri_pos record of entry k, then its triangle index (as integer bits)
 };
 
 struct RtmDevScene {
