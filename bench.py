@@ -162,20 +162,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # dominant kernel: average launch duration with HIP events on the launch stream (this rank's rows)
-    kern_ms = scene.time_render_device(p_local, local.data_ptr(), max(3, min(args.steps, 10)), stream=stream.cuda_stream)
-    local_cnt = scene.render_device(p_local, local.data_ptr(), stats=True, stream=stream.cuda_stream) if world > 1 else cnt
+    # dominant kernel: device time per kernel with HIP event pairs on the launch stream (this rank's rows), and the
+    # counters of the work that kernel really did (rtm_profile_render_device)
+    prof = scene.profile_render_device(p_local, local.data_ptr(), stream=stream.cuda_stream)
+    frame_ms = scene.time_render_device(p_local, local.data_ptr(), max(3, min(args.steps, 10)), stream=stream.cuda_stream)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = rays * args.steps / dt / 1e6
-        abytes = algorithmic_bytes(local_cnt, W, rows)
+        # SURVEY 8(d) per-unit figures x the units the trace kernel processed: 48 B ray + 40 B result per traced ray,
+        # 8 B per cell visited, 76 B per triangle test
+        n_launch = max(1, prof["trace_launches"])
+        abytes = (88.0 * prof["traced_rays"] + 8.0 * prof["cells_visited"] + 76.0 * prof["tri_tests"]) / n_launch
+        kern_ms = prof["trace_ms"] / n_launch
         achieved = abytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(f"{args.workload}_{W}x{H}_{args.spp}spp_n{world}", {}).get("hbm_bytes_per_launch")
-        flops = algorithmic_flops(local_cnt)
+        flops = (9.0 * prof["cells_visited"] + 41.0 * prof["tri_tests"]) / n_launch
+        single = prof["shade_launches"] == 0
         out = {
             "metric": "Mrays/s (primary+shadow) bunny 1200^2 20spp" if args.workload == "bunny" and W == 1200 and args.spp == 20
             else f"Mrays/s (primary+shadow) {args.workload} {W}x{H} {args.spp}spp",
@@ -186,13 +192,20 @@ def main():
             "config": {"workload": f"{args.workload} {W}x{H} at {args.spp} spp, 10 bounces, grid 32^3",
                        "rays_per_frame": rays, "rays_camera": cnt["rays_camera"], "rays_bounce": cnt["rays_bounce"],
                        "rays_shadow": cnt["rays_shadow"], "samples_per_s": W * H * args.spp * args.steps / dt,
+                       "rays_note": "rays the reference casts for this frame (exact counters, pinned to the oracle's). The device path "
+                                    "answers shadow rays whose light is behind the surface (main.rs:96 fails) without tracing them, and "
+                                    f"only rays that enter a model's box reach the trace kernel ({prof['traced_rays']} on this rank)",
                        "parallelism": f"row-interleave x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": abytes,
-                         "note": "scene <= 1.8 MB is L2-resident: the binding limit is FP64 VALU issue + divergence, see valu"},
+                         "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>" if single else "rtf::front_trace_kernel<false, true>",
+                         "kernel_ms": kern_ms, "launches_per_frame": n_launch, "algorithmic_bytes_per_launch": abytes,
+                         "note": "scene and queues are L2/MALL-resident per round: the kernel is bound by the vector-memory "
+                                 "pipeline (per-lane gathers of 80 B triangle records) and FP64 VALU issue, see valu and DESIGN.md"},
             "valu": {"achieved_tflops": flops / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
                      "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "algorithmic_flops_per_launch": flops},
+            "pipeline": {"frame_ms": frame_ms, "shade_ms": prof["shade_ms"], "trace_ms": prof["trace_ms"], "resolve_ms": prof["resolve_ms"],
+                         "shade_launches": prof["shade_launches"], "trace_launches": prof["trace_launches"],
+                         "traced_rays": prof["traced_rays"], "cells_visited": prof["cells_visited"], "tri_tests": prof["tri_tests"]},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload != "soup":
             out["cpu_baseline"] = cpu_baseline(args.workload, W, H)

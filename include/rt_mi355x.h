@@ -146,6 +146,21 @@ int rtm_render_device(const rtm_scene_dev* scene, const rtm_params* params, doub
 int rtm_time_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, int iters,
                            void* stream, double* out_ms_avg);
 
+/* Where a frame's device time goes, for bench.py's roofline line (no counterpart in the reference).  The frame is
+ * rendered twice on `stream`: once with a HIP event pair around every kernel launch, once with the counting
+ * instantiation under the production settings (rtm_render_device's out_stats turns shadow-ray culling off so that
+ * its counters equal the reference's work; these are the counters of the work actually done).  Synchronous. */
+typedef struct rtm_profile {
+    double total_ms;                        /* sum of the kernels below */
+    double shade_ms, trace_ms, resolve_ms;  /* rt_front.h kernels; a single-kernel formulation reports trace_ms only */
+    uint32_t shade_launches, trace_launches;
+    uint64_t traced_rays;                   /* rays that entered a model's box and went through the trace kernel */
+    uint64_t cells_visited, tri_tests;      /* work of the trace kernel */
+    uint64_t rays_total;                    /* camera + bounce + shadow rays issued (culled shadow rays not counted) */
+} rtm_profile;
+int rtm_profile_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, void* stream,
+                              rtm_profile* out);
+
 /* Closest-hit of caller-supplied rays (hit, core.rs:68-92), for differential tests: rays6 = origin xyz,
  * direction xyz (host, n*6); outputs host arrays (obj n, tri n, t n, normal n*3). */
 int rtm_trace_rays(const rtm_scene_dev* scene, uint64_t n, const double* rays6, uint32_t* out_obj_id,

@@ -38,6 +38,12 @@ if not os.path.exists(LIB_PATH):
         "There is no CPU fallback for the render path.")
 
 
+class RtmProfile(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("shade_ms", C.c_double), ("trace_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("shade_launches", C.c_uint32), ("trace_launches", C.c_uint32), ("traced_rays", C.c_uint64),
+                ("cells_visited", C.c_uint64), ("tri_tests", C.c_uint64), ("rays_total", C.c_uint64)]
+
+
 class RtmError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"rtm error {code}: {message}")
@@ -97,6 +103,7 @@ _lib.rtm_scene_upload.argtypes = [C.POINTER(RtmScene), C.POINTER(_vp)]
 _lib.rtm_scene_free.argtypes = [_vp]
 _lib.rtm_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, _vp, _vp, C.POINTER(RtmStats), _vp]
 _lib.rtm_time_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, C.c_int, _vp, C.POINTER(C.c_double)]
+_lib.rtm_profile_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, _vp, C.POINTER(RtmProfile)]
 _lib.rtm_trace_rays.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
 _lib.rtm_tonemap_device.argtypes = [_vp, C.c_uint64, C.c_int, _vp, _vp]
 _lib.rtm_deinterleave_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]
@@ -110,7 +117,7 @@ _lib.rtm_frontend_free.argtypes = [_vp]
 
 EXPORTED_SYMBOLS = (
     "rtm_local_rows", "rtm_init", "rtm_shutdown", "rtm_last_error", "rtm_version", "rtm_set_tuning", "rtm_render", "rtm_scene_upload",
-    "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_trace_rays", "rtm_tonemap_device",
+    "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_profile_render_device", "rtm_trace_rays", "rtm_tonemap_device",
     "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
     "rtm_frontend_size", "rtm_frontend_free")
 
@@ -279,6 +286,12 @@ class Scene:
         _check(_lib.rtm_time_render_device(self.device_handle(), C.byref(params), d_rgb, iters, stream or None,
                                            C.byref(ms)))
         return ms.value
+
+    def profile_render_device(self, params: RtmParams, d_rgb: int, stream: int = 0) -> dict:
+        """rtm_profile_render_device: per-kernel device time and the counters of the work actually done."""
+        pr = RtmProfile()
+        _check(_lib.rtm_profile_render_device(self.device_handle(), C.byref(params), d_rgb, stream or None, C.byref(pr)))
+        return {k: getattr(pr, k) for k, _ in RtmProfile._fields_}
 
     def trace(self, rays6) -> dict:
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)

@@ -418,9 +418,34 @@ bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
 }
 
 // One frame as bands of rows; per band: round 0 (camera rays), then shade/trace rounds until no path is alive.
+struct FrontProfile {  // rtm_profile_render_device: event pairs per launch (kind 0 shade, 1 trace, 2 resolve), item counts
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
+    unsigned long long* d_items = nullptr;
+    bool keep_cull = false;  // counting run under the production culling setting
+};
+
+__global__ void front_sum_items_kernel(const uint32_t* ctr, uint32_t nq, unsigned long long* out) {
+    unsigned long long v = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nq; j += gridDim.x * blockDim.x) v += ctr[(size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS];
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out, v);
+}
+
 int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, uint32_t occ_words, double* d_rgb, uint32_t* d_obj,
-                 uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream) {
+                 uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof = nullptr) {
     const bool stats = d_cnt != nullptr;
+    auto mark = [&](int kind, bool end) {  // event before / after a launch (profile runs only)
+        if (!prof || prof->keep_cull) return;
+        if (!end) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            prof->ev[kind].push_back({a, b});
+            (void)hipEventRecord(a, stream);
+        } else {
+            (void)hipEventRecord(prof->ev[kind].back().second, stream);
+        }
+    };
     const uint32_t tiles_x = (p->width + 7) / 8;
     const size_t band_paths = (size_t)tiles_x * 64u * p->spp;  // paths of one 8-row band
     if (band_paths > 0x3FFFFFFFu / 3u) return rtm_internal_fail(RTM_ERR_INVALID, "width x spp too large for one band of paths");
@@ -464,7 +489,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
         A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
         A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
-        A.cull = stats ? 0u : g_front_cull;
+        A.cull = (stats && !(prof && prof->keep_cull)) ? 0u : g_front_cull;
         A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
         A.occ_words = occ_words;
         A.D = (double*)(B + o_D); A.res_t = (double*)(B + o_rt); A.itD = (double*)(B + o_itD);
@@ -474,6 +499,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.live[0] = (uint32_t*)(B + o_l0); A.live[1] = (uint32_t*)(B + o_l1); A.ctr = (uint32_t*)(B + o_ctr);
         const uint32_t shade_wgs0 = shade_wgs;
         for (uint32_t r = 0; r < rounds; ++r) {
+            mark(0, false);
             if (r == 0) {
                 if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
                 else hipLaunchKernelGGL((rtf::front_shade_kernel<false, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
@@ -481,7 +507,11 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
                 else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
             }
+            mark(0, true);
+            if (prof && prof->d_items && !prof->keep_cull)
+                hipLaunchKernelGGL(front_sum_items_kernel, dim3(32), dim3(256), 0, stream, A.ctr, nq, prof->d_items);
             if (r + 1 < rounds) {  // the last round only finalises
+                mark(1, false);
                 const size_t lds = (size_t)occ_words * 4;
                 if (stats) {
                     if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<true, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
@@ -490,10 +520,13 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<false, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
                     else hipLaunchKernelGGL((rtf::front_trace_kernel<false, false>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
                 }
+                mark(1, true);
             }
             HIP_TRY(hipGetLastError());
         }
+        mark(2, false);
         hipLaunchKernelGGL(rtf::front_resolve_kernel, dim3((A.npix + 255) / 256), block, 0, stream, A, d_rgb);
+        mark(2, true);
         HIP_TRY(hipGetLastError());
     }
     return RTM_OK;
@@ -604,6 +637,67 @@ int rtm_time_render_device(const rtm_scene_dev* sd, const rtm_params* p, double*
     if (rc != RTM_OK) return rc;
     if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("timing: ") + hipGetErrorString(e));
     *out_ms = (double)ms / iters;
+    return RTM_OK;
+}
+
+int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, void* stream_, rtm_profile* out) {
+    if (int rc = need_init()) return rc;
+    if (!sd || !d_rgb || !out) return rtm_internal_fail(RTM_ERR_INVALID, "scene, output or profile is null");
+    if (int rc = check_params(p)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    *out = rtm_profile{};
+    const uint32_t n_rows = rtm_local_rows(p);
+    const bool front = !(p->flags & (RTM_FLAG_KERNEL_V1 | RTM_FLAG_KERNEL_WAVE)) && g_kernel == 2 && front_supported(sd, p);
+    if (!front) {  // one kernel: its time and the reference-equivalent counters
+        double ms = 0.0;
+        if (int rc = rtm_time_render_device(sd, p, d_rgb, 1, stream_, &ms)) return rc;
+        rtm_stats st{};
+        if (int rc = rtm_render_device(sd, p, d_rgb, nullptr, nullptr, &st, stream_)) return rc;
+        out->total_ms = out->trace_ms = ms;
+        out->trace_launches = 1;
+        out->cells_visited = st.cells_visited; out->tri_tests = st.tri_tests;
+        out->rays_total = st.rays_camera + st.rays_bounce + st.rays_shadow;
+        out->traced_rays = st.bbox_tests;
+        return RTM_OK;
+    }
+    uint32_t occ_words = 0;
+    for (uint32_t w : sd->occ_words) {
+        if (occ_words + w > (uint32_t)rtw::kOccLdsWordsMax) break;
+        occ_words += w;
+    }
+    unsigned long long* d_buf = nullptr;  // [0..31] counters of the counting run, [32] traced rays
+    HIP_TRY(hipMalloc((void**)&d_buf, 40 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_buf, 0, 40 * sizeof(unsigned long long), stream));
+    FrontProfile prof;
+    prof.d_items = d_buf + 32;
+    int rc = render_front(sd, p, n_rows, occ_words, d_rgb, nullptr, nullptr, nullptr, stream, &prof);
+    hipError_t e = hipStreamSynchronize(stream);
+    double* const slot[3] = {&out->shade_ms, &out->trace_ms, &out->resolve_ms};
+    for (int k = 0; k < 3; ++k)
+        for (auto& pr : prof.ev[k]) {
+            float ms = 0.f;
+            if (rc == RTM_OK && e == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) *slot[k] += (double)ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    out->shade_launches = (uint32_t)prof.ev[0].size();
+    out->trace_launches = (uint32_t)prof.ev[1].size();
+    out->total_ms = out->shade_ms + out->trace_ms + out->resolve_ms;
+    if (rc == RTM_OK && e == hipSuccess) {
+        FrontProfile cnt_run;
+        cnt_run.keep_cull = true;
+        rc = render_front(sd, p, n_rows, occ_words, d_rgb, nullptr, nullptr, d_buf, stream, &cnt_run);
+        unsigned long long h[40] = {0};
+        if (rc == RTM_OK) e = hipMemcpyAsync(h, d_buf, sizeof h, hipMemcpyDeviceToHost, stream);
+        if (rc == RTM_OK && e == hipSuccess) e = hipStreamSynchronize(stream);
+        out->rays_total = h[0] + h[1] + h[2];
+        out->cells_visited = h[6];
+        out->tri_tests = h[7];
+        out->traced_rays = h[32];
+    }
+    (void)hipFree(d_buf);
+    if (rc != RTM_OK) return rc;
+    if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("profile: ") + hipGetErrorString(e));
     return RTM_OK;
 }
 
