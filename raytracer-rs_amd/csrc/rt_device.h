@@ -45,6 +45,8 @@ RTM_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  //
 RTM_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 RTM_DEV V3 normalize(V3 a) { return a / __builtin_sqrt(dot(a, a)); }  // vec3.rs:213-215
 RTM_DEV V3 ray_at(V3 o, V3 d, double t) { return o + d * t; }         // ray.rs:10-12
+// component-wise select (a struct-typed ?: is lowered to a select of stack addresses, i.e. scratch traffic)
+RTM_DEV V3 sel3(bool c, V3 a, V3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 RTM_DEV double sqdist(V3 a, V3 b) { V3 e = a - b; return dot(e, e); }  // vec3.rs:192-194
 
 // Rust `as u32` on f64 (saturating, NaN -> 0) followed by clamp(0, n-1)   model.rs:268-279

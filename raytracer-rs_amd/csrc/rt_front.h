@@ -27,6 +27,9 @@ using namespace rtd;
 #ifndef RTM_FRONT_OCC
 #define RTM_FRONT_OCC 4  // waves per SIMD the trace kernel's register allocation must leave room for
 #endif
+#ifndef RTM_SHADE_OCC
+#define RTM_SHADE_OCC 3  // waves per SIMD the shade kernel's register allocation must leave room for
+#endif
 #ifndef RTM_FWALK_UNROLL
 #define RTM_FWALK_UNROLL 2
 #endif
@@ -110,7 +113,7 @@ RTM_DEV void flush_counters(const Counters& cnt, unsigned long long* out_cnt) {
 // ================================================================================================
 // shade: round 0 creates the camera rays (main.rs:160-168); later rounds consume and re-issue
 template <bool STATS, bool ROUND0>
-__global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
+__global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
                                                               uint32_t* __restrict__ out_tri, unsigned long long* __restrict__ out_cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     // one sub-list per wave (the grid has exactly nq waves): lists and queues are appended to without atomics.
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                                       u01(rb[0], rb[1]) * (1.0 - 0.0) + 0.0);
                     const V3 refl = d - nn * 2.0 * dot(d, nn);
                     const V3 dif = nn + rnd;
-                    dir0 = metal_new ? refl : dif;
+                    dir0 = sel3(metal_new, refl, dif);
                     norm0 = !metal_new;
                     stU(PU_MAT, mat_new);
                     o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void front_shade_kernel(RtmDevScene S, Fron
                 go2 = n_sh > 1u;
                 {
                     const V3 nd = normalize(dir0);  // vec3.rs:213-215: three divisions by the length
-                    dir0 = norm0 ? nd : dir0;
+                    dir0 = sel3(norm0, nd, dir0);
                 }
                 if (STATS && go0) cnt.v[C_BOUNCE]++;
                 if (STATS) cnt.v[C_SHADOW] += n_sh;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                     const V3 refl = d - nn * 2.0 * dot(d, nn);
                     const V3 diff = nn + rnd;
                     stc3(F_NRM, nn);
-                    stc3(F_BD, metal ? refl : diff);
+                    stc3(F_BD, sel3(metal, refl, diff));
                     stc3(F_DIFF, mk(0, 0, 0));
                     o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
                     li = 0;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock, RTM_WAVE_OCC) void render_wave_kernel(RtmDe
                 }
                 {
                     const V3 nd = normalize(newdir);  // vec3.rs:213-215: three divisions by the length
-                    d = need_norm ? nd : newdir;
+                    d = sel3(need_norm, nd, newdir);
                 }
                 RTW_MARK(3);
                 if (st != ST_FETCH) {
