@@ -453,7 +453,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / band_paths);
     bands_per_chunk = std::min(bands_per_chunk, bands_total);
     const size_t np_max = band_paths * bands_per_chunk;
-    if (np_max * 3u > 0xFFFFFFF0ull) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
+    if (np_max >= (1ull << 30)) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
     // sub-queues (rt_front.h): the shade grid is a multiple of nq waves
     const uint32_t nq = (uint32_t)g_num_cus * g_front_shade_waves_per_cu;  // one sub-list per shade wave
     const uint32_t blocks_max = (uint32_t)((np_max + 63) / 64);
@@ -462,8 +462,8 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t items_max = (size_t)nq * cap_l_max * 3u;
-    const size_t o_D = take(np_max * rtf::PF_COUNT * 8), o_rt = take(np_max * 3 * 8), o_itD = take(items_max * rtf::IT_DCOUNT * 8);
-    const size_t o_U = take(np_max * rtf::PU_COUNT * 4), o_rtri = take(np_max * 3 * 4), o_rm = take(np_max * 3 * 4);
+    const size_t o_D = take(np_max * rtf::PF_COUNT * 8), o_res = take(np_max * 3 * sizeof(rtf::FrontResult)), o_itD = take(items_max * rtf::IT_DCOUNT * 8);
+    const size_t o_U = take(np_max * rtf::PU_COUNT * 4);
     const size_t o_itU = take(items_max * rtf::IU_COUNT * 4), o_l0 = take((size_t)nq * cap_l_max * 4), o_l1 = take((size_t)nq * cap_l_max * 4);
     const size_t o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
     if (off > g_front_ws.bytes) {
@@ -492,8 +492,8 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.cull = (stats && !(prof && prof->keep_cull)) ? 0u : g_front_cull;
         A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
         A.occ_words = occ_words;
-        A.D = (double*)(B + o_D); A.res_t = (double*)(B + o_rt); A.itD = (double*)(B + o_itD);
-        A.U = (uint32_t*)(B + o_U); A.res_tri = (uint32_t*)(B + o_rtri); A.res_m = (uint32_t*)(B + o_rm);
+        A.D = (double*)(B + o_D); A.res = (rtf::FrontResult*)(B + o_res); A.itD = (double*)(B + o_itD);
+        A.U = (uint32_t*)(B + o_U);
         A.itU = (uint32_t*)(B + o_itU);
         A.nq = nq; A.cap_l = ((((A.np + 63u) / 64u) + nq - 1) / nq) * 64u; A.cap_i = A.cap_l * 3u; A.cap_items = nq * A.cap_i;
         A.live[0] = (uint32_t*)(B + o_l0); A.live[1] = (uint32_t*)(B + o_l1); A.ctr = (uint32_t*)(B + o_ctr);

@@ -39,7 +39,10 @@ using namespace rtd;
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 10 bits each, biased by one
 
-// per-path state, structure of arrays: double field f of path p is D[f * np + p], u32 field U[f * np + p]
+// Per-path state, array of structures of arrays: paths in blocks of 64, a block's fields back to back, so double
+// field f of path p is D[at64(PF_COUNT, f, p)] (likewise U, the query results and the trace items).  A wave's
+// accesses of one iteration are 512-byte runs inside ONE ~10 KB region; with whole-frame SoA arrays (hundreds of MB
+// apart) every field sat on its own page and address translation, not HBM, set the pace of the shade kernel.
 enum : int {
     PF_COL = 0,    // colour accumulated along the path (main.rs:59)
     PF_ATT = 3,    // attenuation so far
@@ -66,6 +69,11 @@ enum : uint32_t { IM_SX = 1u << 16, IM_SY = 1u << 17, IM_SZ = 1u << 18 };
 // device counters, one set per sub-queue (each written by the one wave that owns the sub-queue)
 enum : int { CT_LIVE0 = 0, CT_LIVE1 = 1, CT_ITEMS = 2, CT_STRIDE = 4 };
 
+struct __attribute__((aligned(16))) FrontResult {  // one 16-byte store per traced ray
+    double t;
+    uint32_t tri, model;  // model = kNoId: no model was hit
+};
+
 struct FrontArgs {
     uint32_t W, H, spp, max_bounces;
     uint64_t seed;
@@ -79,9 +87,7 @@ struct FrontArgs {
     uint32_t occ_words;
     double* D;
     uint32_t* U;
-    double* res_t;
-    uint32_t* res_tri;
-    uint32_t* res_m;
+    FrontResult* res;           // [at64(3, slot, path)]: what the trace kernel found for a query
     double* itD;
     uint32_t* itU;
     uint32_t cap_items;         // nq * cap_i: stride of the item arrays
@@ -90,6 +96,8 @@ struct FrontArgs {
     uint32_t* live[2];          // [nq][cap_l] each
     uint32_t* ctr;              // [nq][CT_STRIDE]
 };
+
+RTM_DEV size_t at64(int n_fields, int f, size_t i) { return ((i >> 6) * (size_t)n_fields + (size_t)f) * 64u + (i & 63u); }
 
 RTM_DEV uint64_t wave_sum(uint64_t v) {
 #pragma unroll
@@ -127,7 +135,6 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
     const uint32_t n_in_list = ROUND0 ? ((blocks_total + A.nq - 1u - sq) / A.nq) * 64u : my_ctr[round & 1u];
     const uint32_t* __restrict__ live_in = A.live[round & 1u] + (size_t)sq * A.cap_l;
     uint32_t* __restrict__ live_out = A.live[(round + 1u) & 1u] + (size_t)sq * A.cap_l;
-    const size_t np = A.np;
     double* const D = A.D;
     uint32_t* const U = A.U;
     const int K = (int)A.max_bounces;
@@ -147,12 +154,12 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         } else if (valid) {
             p = live_in[idx];
         }
-        auto ldD = [&](int f) -> double { return D[(size_t)f * np + p]; };
-        auto stD = [&](int f, double v) { D[(size_t)f * np + p] = v; };
+        auto ldD = [&](int f) -> double { return D[at64(PF_COUNT, f, p)]; };
+        auto stD = [&](int f, double v) { D[at64(PF_COUNT, f, p)] = v; };
         auto ldD3 = [&](int f) -> V3 { return mk(ldD(f), ldD(f + 1), ldD(f + 2)); };
         auto stD3 = [&](int f, V3 v) { stD(f, v.x); stD(f + 1, v.y); stD(f + 2, v.z); };
-        auto ldU = [&](int f) -> uint32_t { return U[(size_t)f * np + p]; };
-        auto stU = [&](int f, uint32_t v) { U[(size_t)f * np + p] = v; };
+        auto ldU = [&](int f) -> uint32_t { return U[at64(PU_COUNT, f, p)]; };
+        auto stU = [&](int f, uint32_t v) { U[at64(PU_COUNT, f, p)] = v; };
 
         // path -> sample, pixel
         const uint32_t s = p / A.npix, pid = p - s * A.npix;
@@ -197,13 +204,12 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 //      path and is bound by memory latency, not by the few bytes a path in another state would skip
                 fl = ldU(PU_FL);
                 const uint32_t ctr = ldU(PU_CTR);
-                const uint32_t q = p * 3u;
                 o = ldD3(PF_O);
                 const double l_ba0 = ldD(PF_BA0);
                 const uint32_t l_hobj = ldU(PU_HOBJ), l_hmat = ldU(PU_HMAT), l_hkp = ldU(PU_HKP), l_mat = ldU(PU_MAT);
-                const uint32_t l_rm0 = A.res_m[q], l_rm1 = A.res_m[q + 1u], l_rm2 = A.res_m[q + 2u];
-                const double l_rt0 = A.res_t[q], l_rt1 = A.res_t[q + 1u], l_rt2 = A.res_t[q + 2u];
-                const uint32_t l_rtri0 = A.res_tri[q];
+                const FrontResult l_r0 = A.res[at64(3, 0, p)], l_r1 = A.res[at64(3, 1, p)], l_r2 = A.res[at64(3, 2, p)];
+                const uint32_t l_rm0 = l_r0.model, l_rm1 = l_r1.model, l_rm2 = l_r2.model, l_rtri0 = l_r0.tri;
+                const double l_rt0 = l_r0.t, l_rt1 = l_r1.t, l_rt2 = l_r2.t;
                 const double l_sba0 = ldD(PF_SBA), l_sba1 = ldD(PF_SBA + 1);
                 const V3 l_nrm = ldD3(PF_NRM), l_d0 = ldD3(PF_D0), l_col = ldD3(PF_COL);
                 const double l_att = ldD(PF_ATT);
@@ -428,15 +434,14 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 n_items_local += (uint32_t)__popcll(want);
                 if (item) {
                     const size_t it = (size_t)sq * A.cap_i + at + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-                    const size_t cap = A.cap_items;
                     double* const I = A.itD;
-                    I[(IT_O + 0) * cap + it] = o.x; I[(IT_O + 1) * cap + it] = o.y; I[(IT_O + 2) * cap + it] = o.z;
-                    I[(IT_D + 0) * cap + it] = dir.x; I[(IT_D + 1) * cap + it] = dir.y; I[(IT_D + 2) * cap + it] = dir.z;
-                    I[(IT_TM + 0) * cap + it] = tmx; I[(IT_TM + 1) * cap + it] = tmy; I[(IT_TM + 2) * cap + it] = tmz;
-                    I[(IT_TD + 0) * cap + it] = tdx; I[(IT_TD + 1) * cap + it] = tdy; I[(IT_TD + 2) * cap + it] = tdz;
-                    A.itU[(size_t)IU_CELL * cap + it] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
-                    A.itU[(size_t)IU_Q * cap + it] = p * 3u + j;
-                    A.itU[(size_t)IU_M * cap + it] = mword;
+                    I[at64(IT_DCOUNT, IT_O + 0, it)] = o.x; I[at64(IT_DCOUNT, IT_O + 1, it)] = o.y; I[at64(IT_DCOUNT, IT_O + 2, it)] = o.z;
+                    I[at64(IT_DCOUNT, IT_D + 0, it)] = dir.x; I[at64(IT_DCOUNT, IT_D + 1, it)] = dir.y; I[at64(IT_DCOUNT, IT_D + 2, it)] = dir.z;
+                    I[at64(IT_DCOUNT, IT_TM + 0, it)] = tmx; I[at64(IT_DCOUNT, IT_TM + 1, it)] = tmy; I[at64(IT_DCOUNT, IT_TM + 2, it)] = tmz;
+                    I[at64(IT_DCOUNT, IT_TD + 0, it)] = tdx; I[at64(IT_DCOUNT, IT_TD + 1, it)] = tdy; I[at64(IT_DCOUNT, IT_TD + 2, it)] = tdz;
+                    A.itU[at64(IU_COUNT, IU_CELL, it)] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
+                    A.itU[at64(IU_COUNT, IU_Q, it)] = (p << 2) | j;  // query id: path and slot
+                    A.itU[at64(IU_COUNT, IU_M, it)] = mword;
                 }
             }
         };
@@ -503,7 +508,6 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
     const uint64_t dg_begin = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t dg_tr = 0, dg_tw = 0, dg_tt = 0, dg_t0 = 0;  // cycles in refill / walk / test (STATS)
-    const size_t cap = A.cap_items;
     // the wave's position in the queue: it owns sub-queues sq, sq + waves, sq + 2 waves, ... and reads each in order
     const uint32_t trace_waves = gridDim.x * (kBlock / 64);
     uint32_t sq = blockIdx.x * (kBlock / 64) + (tid >> 6);
@@ -528,9 +532,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     uint64_t dg_steps = 0, dg_step_lanes = 0, dg_walks = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_refills = 0, dg_refill_lanes = 0;  // STATS only, wave-uniform
 
     auto finish_ray = [&]() __attribute__((always_inline)) {
-        A.res_t[q] = bt;
-        A.res_tri[q] = btri;
-        A.res_m[q] = bm;
+        FrontResult r;
+        r.t = bt; r.tri = btri; r.model = bm;
+        A.res[at64(3, (int)(q & 3u), q >> 2)] = r;
         st = TS_IDLE;
     };
     auto model_result = [&](const bool hit, const uint32_t m, const uint32_t mobj) __attribute__((always_inline)) {
@@ -572,14 +576,14 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 const uint32_t avail = pool_end - pool_next;
                 if (st == TS_IDLE && rank < avail) {
                     const size_t it = (size_t)pool_next + rank;
-                    o = mk(I[(IT_O + 0) * cap + it], I[(IT_O + 1) * cap + it], I[(IT_O + 2) * cap + it]);
-                    d = mk(I[(IT_D + 0) * cap + it], I[(IT_D + 1) * cap + it], I[(IT_D + 2) * cap + it]);
-                    tmx = I[(IT_TM + 0) * cap + it]; tmy = I[(IT_TM + 1) * cap + it]; tmz = I[(IT_TM + 2) * cap + it];
-                    tdx = I[(IT_TD + 0) * cap + it]; tdy = I[(IT_TD + 1) * cap + it]; tdz = I[(IT_TD + 2) * cap + it];
-                    const uint32_t cw = IU[(size_t)IU_CELL * cap + it];
+                    o = mk(I[at64(IT_DCOUNT, IT_O + 0, it)], I[at64(IT_DCOUNT, IT_O + 1, it)], I[at64(IT_DCOUNT, IT_O + 2, it)]);
+                    d = mk(I[at64(IT_DCOUNT, IT_D + 0, it)], I[at64(IT_DCOUNT, IT_D + 1, it)], I[at64(IT_DCOUNT, IT_D + 2, it)]);
+                    tmx = I[at64(IT_DCOUNT, IT_TM + 0, it)]; tmy = I[at64(IT_DCOUNT, IT_TM + 1, it)]; tmz = I[at64(IT_DCOUNT, IT_TM + 2, it)];
+                    tdx = I[at64(IT_DCOUNT, IT_TD + 0, it)]; tdy = I[at64(IT_DCOUNT, IT_TD + 1, it)]; tdz = I[at64(IT_DCOUNT, IT_TD + 2, it)];
+                    const uint32_t cw = IU[at64(IU_COUNT, IU_CELL, it)];
                     ix = (int)(cw & 1023u) - 1; iy = (int)((cw >> 10) & 1023u) - 1; iz = (int)((cw >> 20) & 1023u) - 1;
-                    q = IU[(size_t)IU_Q * cap + it];
-                    const uint32_t mw = IU[(size_t)IU_M * cap + it];
+                    q = IU[at64(IU_COUNT, IU_Q, it)];
+                    const uint32_t mw = IU[at64(IU_COUNT, IU_M, it)];
                     model_i = mw & 0xFFFFu;
                     sgn = mw;
                     have = false; fresh = true; open = false;
@@ -782,12 +786,11 @@ __global__ __launch_bounds__(kBlock) void front_resolve_kernel(FrontArgs A, doub
     const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
     const uint32_t lyc = (tile / A.tiles_x) * 8u + (in >> 3);
     if (!(x < A.W && lyc < A.rows)) return;
-    const size_t np = A.np;
     const double n_spp = (double)A.spp;
     V3 px = mk(0, 0, 0);
     for (uint32_t s = 0; s < A.spp; ++s) {
         const size_t p = (size_t)s * A.npix + pid;
-        px = px + mk(A.D[(PF_COL + 0) * np + p], A.D[(PF_COL + 1) * np + p], A.D[(PF_COL + 2) * np + p]) / n_spp;
+        px = px + mk(A.D[at64(PF_COUNT, PF_COL + 0, p)], A.D[at64(PF_COUNT, PF_COL + 1, p)], A.D[at64(PF_COUNT, PF_COL + 2, p)]) / n_spp;
     }
     const size_t oi = (size_t)(A.row0 + lyc) * A.W + x;
     out_rgb[oi * 3] = px.x;
