@@ -392,6 +392,40 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             std::memcpy(&rec[e * 10 + 9], &bits, 8);
         }
         if ((rc = upload(sd, rec, &D.cell_rec))) return fail(rc);
+        // Per cell: [start, end) and, for lists of at most 32 entries, one mask per arrival direction.  The reference tests
+        // every entry of every cell it visits; an entry whose triangle is also listed in the cell the DDA step came from
+        // was tested one step earlier with the same ray and was not accepted (the walk would have ended there,
+        // core.rs:147-149), so testing it again cannot change anything: its bit is cleared.
+        {
+            const uint32_t n = M.cells_per_side;
+            std::vector<uint32_t> info(n3 * 8);
+            std::vector<uint32_t> sorted;
+            for (size_t c = 0; c < n3; ++c) {
+                const uint32_t b = start[c], e = start[c + 1], len = e - b;
+                info[c * 8] = b;
+                info[c * 8 + 1] = e;
+                const uint32_t all = len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                const uint32_t cx = (uint32_t)(c % n), cy = (uint32_t)((c / n) % n), cz = (uint32_t)(c / ((size_t)n * n));
+                for (int a = 0; a < 6; ++a) {
+                    uint32_t mask = all;
+                    // arrival code a = axis * 2 + (step > 0): the previous cell is one step back along that axis
+                    const int axis = a >> 1, back = (a & 1) ? -1 : 1;
+                    const long px = (long)cx + (axis == 0 ? back : 0), py = (long)cy + (axis == 1 ? back : 0), pz = (long)cz + (axis == 2 ? back : 0);
+                    if (len > 0 && len <= 32 && px >= 0 && py >= 0 && pz >= 0 && px < (long)n && py < (long)n && pz < (long)n) {
+                        const size_t pc = ((size_t)pz * n + (size_t)py) * n + (size_t)px;
+                        const uint32_t pb = start[pc], pe = start[pc + 1];
+                        if (pe > pb) {
+                            sorted.assign(idx.begin() + pb, idx.begin() + pe);
+                            std::sort(sorted.begin(), sorted.end());
+                            for (uint32_t i = 0; i < len; ++i)
+                                if (std::binary_search(sorted.begin(), sorted.end(), idx[b + i])) mask &= ~(1u << i);
+                        }
+                    }
+                    info[c * 8 + 2 + a] = mask;
+                }
+            }
+            if ((rc = upload(sd, info, &D.cell_info))) return fail(rc);
+        }
         if ((rc = upload(sd, start, &D.cell_start)) || (rc = upload(sd, idx, &D.tri_idx)) || (rc = upload(sd, pos, &D.tri_pos)) ||
             (rc = upload(sd, nrm, &D.tri_nrm)) || (rc = upload(sd, occ, &D.occupancy)))
             return fail(rc);

@@ -523,7 +523,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     int ix = 0, iy = 0, iz = 0;
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
-    uint32_t k = 0, k_end = 0, m_tri = 0;
+    uint32_t k = 0, k_end = 0, m_tri = 0;  // [k, k_end): the rest of the current cell's list, k = first entry of the 32-entry window
+    uint32_t wmask = 0, mw = 0, arr = 6;   // untested entries of the window; the cell's mask for the arrival direction arr
+    bool winit = false;                    // the window of a newly opened cell has not been set up yet
     double m_t = 0.0;
     bool have = false, fresh = false, open = false;
     double bt = 0.0;  // closest model hit of this ray so far, over the models visited (core.rs:79-83)
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         tmx = ax_ ? nx_ : tmx;                                                 \
         tmy = ay_ ? ny_ : tmy;                                                 \
         tmz = az_ ? nz_ : tmz;                                                 \
+        arr = ax_ ? ((sgn & IM_SX) ? 1u : 0u) : (ay_ ? ((sgn & IM_SY) ? 3u : 2u) : ((sgn & IM_SZ) ? 5u : 4u)); \
     } while (0)
 
     for (;;) {
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const uint32_t mw = IU[at64(IU_COUNT, IU_M, it)];
                     model_i = mw & 0xFFFFu;
                     sgn = mw;
-                    have = false; fresh = true; open = false;
+                    have = false; fresh = true; open = false; arr = 6u;
                     bm = kNoId; btri = kNoId; bobj = kNoId; bt = 0.0;
                     st = TS_TRAV;
                 }
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         tdy = ((double)sy * M.cell[1]) / d.y;
                         tdz = ((double)sz * M.cell[2]) / d.z;
                         sgn = (sx > 0 ? IM_SX : 0u) | (sy > 0 ? IM_SY : 0u) | (sz > 0 ? IM_SZ : 0u);
-                        have = false; fresh = true; open = false;
+                        have = false; fresh = true; open = false; arr = 6u;
                         st = TS_TRAV;
                     }
                 }
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         const RtmDevModel& M = S.models[mm];
         // (wave-uniform by construction; said explicitly so that they live in SGPRs and cost no waits in the loop)
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.n), M_obj = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.obj);
-        const gptr<uint32_t> cell_start = as_global(M.cell_start);
+        const gptr<uint32_t> cell_info = as_global(M.cell_info);
         const gptr<double> cell_rec = as_global(M.cell_rec);
         const gptr<uint32_t> occ_glb = as_global(M.occupancy);
         const bool occ_in_lds = occ_base != 0xFFFFFFFFu;
@@ -686,8 +689,12 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                             if (ALL_LDS || occ_in_lds) word = occ_lds[occ_base + (cell >> 5)];
                             else word = occ_glb[cell >> 5];
                             if ((word >> (cell & 31u)) & 1u) {  // non-empty: the list is [k, k_end), k < k_end
-                                k = cell_start[cell];
-                                k_end = cell_start[cell + 1];
+                                // list range and the arrival mask: one 32-byte record (used by the next test phase)
+                                const gptr<uint32_t> ci = cell_info + (size_t)cell * 8;
+                                k = ci[0];
+                                k_end = ci[1];
+                                mw = ci[2 + (arr < 6u ? arr : 0u)];
+                                winit = true;
                                 open = true;
                             }
                         } else {  // left the grid without a hit
@@ -703,13 +710,24 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
                     // the same side).  Entries are applied in list order (core.rs:140-142).
-                    const uint32_t left = k_end - k;
-                    const uint32_t cntw = left < (uint32_t)RTM_FTRI_WIDE ? left : (uint32_t)RTM_FTRI_WIDE;
+                    if (winit) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
+                        const uint32_t len = k_end - k;
+                        const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                        wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
+                        winit = false;
+                    }
                     uint32_t ti[RTM_FTRI_WIDE];
                     double tt[RTM_FTRI_WIDE];
                     bool ok[RTM_FTRI_WIDE];
+                    uint32_t cntw = 0;
 #pragma unroll
-                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) ti[j] = k + ((uint32_t)j < cntw ? (uint32_t)j : 0u);  // list positions
+                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) {  // the next untested entries, in list order
+                        const bool any = wmask != 0u;
+                        const uint32_t b = any ? (uint32_t)__builtin_ctz(wmask) : 0u;
+                        ti[j] = k + b;
+                        wmask &= wmask - 1u;
+                        cntw += any ? 1u : 0u;
+                    }
 #pragma unroll
                     for (int j = 0; j < RTM_FTRI_WIDE; ++j) {
                         tt[j] = 0.0;
@@ -741,8 +759,15 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         have = have || take;
                     }
                     if (STATS) cnt.v[C_TRI] += cntw;
-                    k += cntw;
-                    open = k < k_end;
+                    if (wmask == 0u) {  // window done: the next 32 entries of a long list, or the cell is finished
+                        if (k_end - k > 32u) {
+                            k += 32u;
+                            const uint32_t len = k_end - k;
+                            wmask = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                        } else {
+                            open = false;
+                        }
+                    }
                 }
                 if (STATS) dg_tt += __builtin_amdgcn_s_memtime() - dg_t0;
             }
