@@ -487,7 +487,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / band_paths);
     bands_per_chunk = std::min(bands_per_chunk, bands_total);
     const size_t np_max = band_paths * bands_per_chunk;
-    if (np_max >= (1ull << 30)) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
+    if (np_max + (size_t)64 * 64 * 1024 >= (1ull << 30)) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
     // sub-queues (rt_front.h): the shade grid is a multiple of nq waves
     const uint32_t nq = (uint32_t)g_num_cus * g_front_shade_waves_per_cu;  // one sub-list per shade wave
     const uint32_t blocks_max = (uint32_t)((np_max + 63) / 64);
@@ -496,8 +496,9 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t items_max = (size_t)nq * cap_l_max * 3u;
-    const size_t o_D = take(np_max * rtf::PF_COUNT * 8), o_res = take(np_max * 3 * sizeof(rtf::FrontResult)), o_itD = take(items_max * rtf::IT_DCOUNT * 8);
-    const size_t o_U = take(np_max * rtf::PU_COUNT * 4);
+    const size_t slots_max = (size_t)nq * cap_l_max;  // path slots (>= np_max: every wave's share is rounded up to whole blocks)
+    const size_t o_D = take(slots_max * rtf::PF_COUNT * 8), o_res = take(slots_max * 3 * sizeof(rtf::FrontResult)), o_itD = take(items_max * rtf::IT_DCOUNT * 8);
+    const size_t o_U = take(slots_max * rtf::PU_COUNT * 4);
     const size_t o_itU = take(items_max * rtf::IU_COUNT * 4), o_l0 = take((size_t)nq * cap_l_max * 4), o_l1 = take((size_t)nq * cap_l_max * 4);
     const size_t o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
     if (off > g_front_ws.bytes) {

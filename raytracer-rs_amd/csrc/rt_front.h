@@ -80,7 +80,8 @@ struct FrontArgs {
     uint32_t row_begin, row_stride, flags;
     uint32_t row0, rows;        // this band: local rows [row0, row0 + rows)
     uint32_t tiles_x, n_tiles;  // 8x8 pixel tiles over W x rows; pixel ids are tile-major
-    uint32_t npix, np;          // npix = n_tiles * 64 (ragged tiles padded), np = npix * spp paths, p = sample * npix + pixel id
+    uint32_t npix, np;          // npix = n_tiles * 64 (ragged tiles padded), np = npix * spp paths.  Logical path = 64-path block
+                                // (sample, tile) x lane; block b is stored at slot (b % nq) * cap_l + (b / nq) * 64: wave b % nq owns it
     uint32_t cull;              // 1: shadow queries that cannot contribute (eff <= 0.001) are not traced
     uint32_t refill;            // trace kernel: fetch new items when at least this many lanes of a wave are idle
     uint32_t t_test_frac, t_min_lanes;
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         bool valid = idx < n_in_list;
         uint32_t p = 0;
         if (ROUND0) {
-            p = (k * A.nq + sq) * 64u + lane;
-            valid = p < A.np;
-            if (!valid) p = 0;
+            p = sq * A.cap_l + k * 64u + lane;            // storage slot: the wave's paths are contiguous in memory
+            valid = (k * A.nq + sq) < blocks_total;       // logical block (sample, tile), dealt round-robin for balance
+            if (!valid) p = sq * A.cap_l;
         } else if (valid) {
             p = live_in[idx];
         }
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         auto stU = [&](int f, uint32_t v) { U[at64(PU_COUNT, f, p)] = v; };
 
         // path -> sample, pixel
-        const uint32_t s = p / A.npix, pid = p - s * A.npix;
-        const uint32_t tile = pid >> 6, in = pid & 63u;
+        const uint32_t blk = ((p % A.cap_l) >> 6) * A.nq + p / A.cap_l;  // logical block of the slot
+        const uint32_t s = blk / A.n_tiles, tile = blk - s * A.n_tiles, in = p & 63u;
         const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
         const uint32_t lyc = (tile / A.tiles_x) * 8u + (in >> 3);
         if (ROUND0 && !(x < A.W && lyc < A.rows)) valid = false;  // padding of a ragged tile: never alive
@@ -525,9 +526,16 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
     uint32_t k = 0, k_end = 0, m_tri = 0;  // [k, k_end): the rest of the current cell's list, k = first entry of the 32-entry window
     uint32_t wmask = 0, mw = 0, arr = 6;   // untested entries of the window; the cell's mask for the arrival direction arr
-    bool winit = false;                    // the window of a newly opened cell has not been set up yet
     double m_t = 0.0;
-    bool have = false, fresh = false, open = false;
+    // per-ray flags, kept as bits of one VGPR: as separate bools they live in SGPR lane masks and every join of the
+    // divergent control flow below costs a handful of scalar mask merges per flag (half of the kernel's instructions)
+    enum : uint32_t {
+        F_HAVE = 1u,   // a triangle of the current cell was accepted (core.rs:140-149)
+        F_FRESH = 2u,  // the entry cell has not been visited yet: no DDA step before it
+        F_OPEN = 4u,   // the current cell's list is not exhausted
+        F_WINIT = 8u   // the window of a newly opened cell has not been set up yet
+    };
+    uint32_t fl = 0;
     double bt = 0.0;  // closest model hit of this ray so far, over the models visited (core.rs:79-83)
     uint32_t bm = kNoId, btri = kNoId, bobj = kNoId;
     bool exhausted = sq >= A.nq;
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const uint32_t mw = IU[at64(IU_COUNT, IU_M, it)];
                     model_i = mw & 0xFFFFu;
                     sgn = mw;
-                    have = false; fresh = true; open = false; arr = 6u;
+                    fl = F_FRESH; arr = 6u;
                     bm = kNoId; btri = kNoId; bobj = kNoId; bt = 0.0;
                     st = TS_TRAV;
                 }
@@ -632,7 +640,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         tdy = ((double)sy * M.cell[1]) / d.y;
                         tdz = ((double)sz * M.cell[2]) / d.z;
                         sgn = (sx > 0 ? IM_SX : 0u) | (sy > 0 ? IM_SY : 0u) | (sz > 0 ? IM_SZ : 0u);
-                        have = false; fresh = true; open = false; arr = 6u;
+                        fl = F_FRESH; arr = 6u;
                         st = TS_TRAV;
                     }
                 }
@@ -663,23 +671,23 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             // A traversing lane is either WALKING (one DDA step and one bitmap probe per cell) or TESTING (its
             // cell's list is open); each iteration runs one of the two activities, whichever has the lanes.
             bool mine = st == TS_TRAV && model_i == mm;
-            if (mine && !open && have) {  // core.rs:147-149: the first cell with any accepted hit ends the walk
+            if (mine && (fl & (F_OPEN | F_HAVE)) == F_HAVE) {  // core.rs:147-149: the first cell with any accepted hit ends the walk
                 if (STATS) cnt.v[C_MHIT]++;
                 model_result(true, mm, M_obj);
                 model_i = mm + 1;
                 if (last_model) finish_ray(); else st = TS_ENTER;
                 mine = false;
             }
-            const uint32_t nW = (uint32_t)__popcll(__ballot(mine && !open));
-            const uint32_t nT = (uint32_t)__popcll(__ballot(mine && open));
+            const uint32_t nW = (uint32_t)__popcll(__ballot(mine && !(fl & F_OPEN)));
+            const uint32_t nT = (uint32_t)__popcll(__ballot(mine && (fl & F_OPEN)));
             if (nW + nT == 0u) break;
             if (nT == 0u || (nW != 0u && nT * 64u < A.t_test_frac * (nW + nT))) {
                 if (STATS) { dg_walks++; dg_walk_lanes += nW; dg_t0 = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
                 for (int u = 0; u < RTM_FWALK_UNROLL; ++u) {
-                    if (st == TS_TRAV && model_i == mm && !open) {
-                        if (!fresh) RTF_DDA_ADVANCE();  // core.rs:151-167
-                        fresh = false;
+                    if (st == TS_TRAV && model_i == mm && !(fl & F_OPEN)) {
+                        if (!(fl & F_FRESH)) RTF_DDA_ADVANCE();  // core.rs:151-167
+                        fl &= ~F_FRESH;
                         if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {  // core.rs:129-134
                             if (STATS) cnt.v[C_CELLS]++;
                             const uint32_t cell = ((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix;
@@ -694,8 +702,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                                 k = ci[0];
                                 k_end = ci[1];
                                 mw = ci[2 + (arr < 6u ? arr : 0u)];
-                                winit = true;
-                                open = true;
+                                fl |= F_WINIT | F_OPEN;
                             }
                         } else {  // left the grid without a hit
                             model_i = mm + 1;
@@ -706,15 +713,16 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 if (STATS) dg_tw += __builtin_amdgcn_s_memtime() - dg_t0;
             } else {
                 if (STATS) { dg_steps++; dg_step_lanes += nT; dg_t0 = __builtin_amdgcn_s_memtime(); }
-                if (mine && open) {
+                if (mine && (fl & F_OPEN)) {
+                    bool have = (fl & F_HAVE) != 0u;
                     // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
                     // the same side).  Entries are applied in list order (core.rs:140-142).
-                    if (winit) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
+                    if (fl & F_WINIT) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
                         const uint32_t len = k_end - k;
                         const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
                         wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
-                        winit = false;
+                        fl &= ~F_WINIT;
                     }
                     uint32_t ti[RTM_FTRI_WIDE];
                     double tt[RTM_FTRI_WIDE];
@@ -758,6 +766,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         m_tri = take ? ti[j] : m_tri;
                         have = have || take;
                     }
+                    fl = (fl & ~F_HAVE) | (have ? F_HAVE : 0u);
                     if (STATS) cnt.v[C_TRI] += cntw;
                     if (wmask == 0u) {  // window done: the next 32 entries of a long list, or the cell is finished
                         if (k_end - k > 32u) {
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                             const uint32_t len = k_end - k;
                             wmask = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
                         } else {
-                            open = false;
+                            fl &= ~F_OPEN;
                         }
                     }
                 }
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             if ((uint32_t)__popcll(still) < A.t_min_lanes && __ballot(st == TS_ENTER)) break;
         }
         // a hit accepted in the last iteration (the loop may leave before its next top)
-        if (st == TS_TRAV && model_i == mm && !open && have) {
+        if (st == TS_TRAV && model_i == mm && (fl & (F_OPEN | F_HAVE)) == F_HAVE) {
             if (STATS) cnt.v[C_MHIT]++;
             model_result(true, mm, M_obj);
             model_i = mm + 1;
@@ -814,7 +823,8 @@ __global__ __launch_bounds__(kBlock) void front_resolve_kernel(FrontArgs A, doub
     const double n_spp = (double)A.spp;
     V3 px = mk(0, 0, 0);
     for (uint32_t s = 0; s < A.spp; ++s) {
-        const size_t p = (size_t)s * A.npix + pid;
+        const uint32_t blk = s * A.n_tiles + tile;
+        const size_t p = (size_t)(blk % A.nq) * A.cap_l + (size_t)(blk / A.nq) * 64u + in;  // the slot the shade kernel used
         px = px + mk(A.D[at64(PF_COUNT, PF_COL + 0, p)], A.D[at64(PF_COUNT, PF_COL + 1, p)], A.D[at64(PF_COUNT, PF_COL + 2, p)]) / n_spp;
     }
     const size_t oi = (size_t)(A.row0 + lyc) * A.W + x;
