@@ -23,8 +23,11 @@ same = np.array_equal(gr["obj_id"], cr["obj_id"]) and np.array_equal(gr["tri_id"
 bits = int((gr["rgb"].view(np.uint64) != cr["rgb"].view(np.uint64)).sum())
 rays = sum(cr["counters"][k] for k in ("rays_camera", "rays_bounce", "rays_shadow"))
 print(f"parity 256^2 1spp: ids equal {same}, differing f64 words {bits}, counters equal {gr['counters'] == cr['counters']}; oracle {tc:.1f}s = {rays/tc/1e6:.2f} Mrays/s", flush=True)
+gn = s.render(spp=1, seed=1, width=256, height=256)
+gw = s.render(spp=1, seed=1, width=256, height=256, kernel_wave=True)
+print("production path (culling, arrival masks) bits equal:", np.array_equal(gn["rgb"], cr["rgb"]), " wave kernel:", np.array_equal(gw["rgb"], cr["rgb"]), flush=True)
 print("counters", cr["counters"], flush=True)
-for spp in (1, 4):
+for spp in (1, 4, 20):
     p = R.make_params(3840, 3840, spp=spp, seed=0)
     buf = torch.empty(3840 * 3840 * 3, dtype=torch.float64, device="cuda")
     st = s.render_device(p, buf.data_ptr(), stats=True)
