@@ -35,6 +35,7 @@ static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile 
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
 static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); env RTM_KERNEL=wave|front
+static bool g_front_debug_rounds = false;
 static uint32_t g_front_refill = 16, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
 struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
     char* base = nullptr;
@@ -175,6 +176,7 @@ struct rtm_scene_dev {
     std::vector<void*> allocs;
     std::vector<uint32_t> occ_words;  // per model: words of its cell-occupancy bitmap
     uint32_t max_n = 0;               // largest cells_per_side
+    uint64_t max_list = 0;            // largest n_tri_idx
     int device;
 };
 
@@ -274,6 +276,7 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : 2;
     if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
+    g_front_debug_rounds = std::getenv("RTM_FRONT_DEBUG_ROUNDS") != nullptr;
     if (const char* e = std::getenv("RTM_FRONT_CULL")) g_front_cull = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(64ll, std::atoll(e));
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
@@ -365,6 +368,7 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             D.hc2[c] = D.hc[c] * 2.0;
         }
         sd->max_n = std::max(sd->max_n, M.cells_per_side);
+        sd->max_list = std::max<uint64_t>(sd->max_list, M.n_tri_idx);
         D.n = M.cells_per_side; D.n_tris = M.n_tris; D.mat = M.mat_idx; D.obj = M.obj_idx;
         const size_t n3 = (size_t)M.cells_per_side * M.cells_per_side * M.cells_per_side;
         std::vector<uint32_t> start(n3 + 2, 0), occ((n3 + 31) / 32, 0);
@@ -448,7 +452,7 @@ namespace {
 bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
     // packed cell coordinates and model indices (rt_front.h); one 8-row band of paths must fit the workspace budget
     const uint64_t band_paths = (uint64_t)((p->width + 7) / 8) * 64u * p->spp;
-    return sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && band_paths <= (64ull << 20);
+    return sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && sd->max_list < rtf::kMaxListEntries && band_paths <= (64ull << 20);
 }
 
 // One frame as bands of rows; per band: round 0 (camera rays), then shade/trace rounds until no path is alive.
@@ -497,9 +501,10 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t items_max = (size_t)nq * cap_l_max * 3u;
     const size_t slots_max = (size_t)nq * cap_l_max;  // path slots (>= np_max: every wave's share is rounded up to whole blocks)
-    const size_t o_D = take(slots_max * rtf::PF_COUNT * 8), o_res = take(slots_max * 3 * sizeof(rtf::FrontResult)), o_itD = take(items_max * rtf::IT_DCOUNT * 8);
-    const size_t o_U = take(slots_max * rtf::PU_COUNT * 4);
-    const size_t o_itU = take(items_max * rtf::IU_COUNT * 4), o_l0 = take((size_t)nq * cap_l_max * 4), o_l1 = take((size_t)nq * cap_l_max * 4);
+    const size_t o_D0 = take(slots_max * rtf::PF_COUNT * 8), o_D1 = take(slots_max * rtf::PF_COUNT * 8);
+    const size_t o_U0 = take(slots_max * rtf::PU_COUNT * 4), o_U1 = take(slots_max * rtf::PU_COUNT * 4);
+    const size_t o_fin = take(slots_max * 3 * 8), o_res = take(slots_max * 3 * sizeof(rtf::FrontResult));
+    const size_t o_itD = take(items_max * rtf::IT_DCOUNT * 8), o_itU = take(items_max * rtf::IU_COUNT * 4);
     const size_t o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
     if (off > g_front_ws.bytes) {
         if (g_front_ws.base) HIP_TRY(hipFree(g_front_ws.base));
@@ -527,11 +532,11 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.cull = (stats && !(prof && prof->keep_cull)) ? 0u : g_front_cull;
         A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
         A.occ_words = occ_words;
-        A.D = (double*)(B + o_D); A.res = (rtf::FrontResult*)(B + o_res); A.itD = (double*)(B + o_itD);
-        A.U = (uint32_t*)(B + o_U);
-        A.itU = (uint32_t*)(B + o_itU);
+        A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
+        A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);
+        A.itD = (double*)(B + o_itD); A.itU = (uint32_t*)(B + o_itU);
         A.nq = nq; A.cap_l = ((((A.np + 63u) / 64u) + nq - 1) / nq) * 64u; A.cap_i = A.cap_l * 3u; A.cap_items = nq * A.cap_i;
-        A.live[0] = (uint32_t*)(B + o_l0); A.live[1] = (uint32_t*)(B + o_l1); A.ctr = (uint32_t*)(B + o_ctr);
+        A.ctr = (uint32_t*)(B + o_ctr);
         const uint32_t shade_wgs0 = shade_wgs;
         for (uint32_t r = 0; r < rounds; ++r) {
             mark(0, false);
@@ -558,6 +563,20 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 mark(1, true);
             }
             HIP_TRY(hipGetLastError());
+            if (g_front_debug_rounds) {  // RTM_FRONT_DEBUG_ROUNDS=1: list lengths after every round (synchronises; diagnostics only)
+                std::vector<uint32_t> h((size_t)nq * rtf::CT_STRIDE);
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipMemcpy(h.data(), A.ctr, h.size() * 4, hipMemcpyDeviceToHost));
+                uint64_t live = 0, items = 0;
+                uint32_t live_max = 0, items_max = 0;
+                for (uint32_t j = 0; j < nq; ++j) {
+                    const uint32_t l = h[(size_t)j * rtf::CT_STRIDE + ((r + 1u) & 1u)], it = h[(size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS];
+                    live += l; items += it;
+                    live_max = std::max(live_max, l); items_max = std::max(items_max, it);
+                }
+                std::fprintf(stderr, "[rtm front] round %u: live %llu (max %u per sub-list of %u), items %llu (max %u)\n", r,
+                             (unsigned long long)live, live_max, nq, (unsigned long long)items, items_max);
+            }
         }
         mark(2, false);
         hipLaunchKernelGGL(rtf::front_resolve_kernel, dim3((A.npix + 255) / 256), block, 0, stream, A, d_rgb);

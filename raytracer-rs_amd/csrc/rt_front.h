@@ -37,6 +37,7 @@ using namespace rtd;
 #define RTM_FTRI_WIDE 4
 #endif
 constexpr int kBlock = 256;
+constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multiplied by 10 in 32 bits
 constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 10 bits each, biased by one
 
 // Per-path state, array of structures of arrays: paths in blocks of 64, a block's fields back to back, so double
@@ -52,15 +53,18 @@ enum : int {
     PF_SBA = 11,   // closest analytic hits of the two shadow queries
     PF_NRM = 13,   // shading normal of the vertex being shaded
     PF_DIFF = 16,  // diffuse sum so far (scenes with more than two lights)
-    PF_COUNT = 19
+    PF_HELD = 19,  // t of slot 0's model hit, kept while further batches of shadow rays are traced (more than two lights)
+    PF_COUNT = 20
 };
-enum : int { PU_FL = 0, PU_CTR = 1, PU_HOBJ = 2, PU_HMAT = 3, PU_HKP = 4, PU_MAT = 5, PU_COUNT = 6 };
+enum : int { PU_FL = 0, PU_CTR = 1, PU_HOBJ = 2, PU_HMAT = 3, PU_HKP = 4, PU_MAT = 5, PU_HOME = 6 /* slot in round 0: names pixel and sample */,
+             PU_HTRI = 7, PU_HM = 8 /* with PF_HELD */, PU_COUNT = 9 };
 enum : uint32_t {
     FB_HASV = 1u,                              // a shaded vertex waits for its shadow results
     FB_FOUND0 = 2u, FB_FOUND1 = 4u, FB_FOUND2 = 8u,  // query j has an analytic hit
     FB_TQ0 = 16u, FB_TQ1 = 32u, FB_TQ2 = 64u,        // query j went to the trace kernel: res_*[3p+j] holds its model hit
     FB_C1 = 128u, FB_C2 = 256u,                      // shadow query j faces its light (eff > 0.001, main.rs:96)
-    FB_NSH_SHIFT = 9u                                // two bits: shadow queries in flight (0..2)
+    FB_NSH_SHIFT = 9u,                               // two bits: shadow queries in flight (0..2)
+    FB_HELD = 2048u                                  // slot 0's answer is in PF_HELD / PU_HTRI / PU_HM
 };
 // trace items, structure of arrays over the item index
 enum : int { IT_O = 0, IT_D = 3, IT_TM = 6, IT_TD = 9, IT_DCOUNT = 12 };
@@ -86,15 +90,15 @@ struct FrontArgs {
     uint32_t refill;            // trace kernel: fetch new items when at least this many lanes of a wave are idle
     uint32_t t_test_frac, t_min_lanes;
     uint32_t occ_words;
-    double* D;
-    uint32_t* U;
+    double* D[2];               // path state, streamed from one buffer to the other every round
+    uint32_t* U[2];
+    double* fin;                // [at64(3, c, home slot)]: colour of a finished sample
     FrontResult* res;           // [at64(3, slot, path)]: what the trace kernel found for a query
     double* itD;
     uint32_t* itU;
     uint32_t cap_items;         // nq * cap_i: stride of the item arrays
     uint32_t nq;                // sub-queues: wave w of the shade kernel reads live sub-list w % nq and appends to the same one
     uint32_t cap_l, cap_i;      // capacity of one live sub-list / one item sub-queue (cap_i = 3 * cap_l)
-    uint32_t* live[2];          // [nq][cap_l] each
     uint32_t* ctr;              // [nq][CT_STRIDE]
 };
 
@@ -125,19 +129,23 @@ template <bool STATS, bool ROUND0>
 __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
                                                               uint32_t* __restrict__ out_tri, unsigned long long* __restrict__ out_cnt) {
     const uint32_t lane = threadIdx.x & 63u;
-    // one sub-list per wave (the grid has exactly nq waves): lists and queues are appended to without atomics.
-    // (Device-scope atomics resolve outside the per-XCD L2 on this part; ~10 ns each when they share an address,
-    // which made a single queue counter the bottleneck of both kernels.)
+    // One sub-list per wave (the grid has exactly nq waves): nothing is appended with atomics.  (Device-scope atomics
+    // resolve outside the per-XCD L2 on this part; ~10 ns each when they share an address, which made a single queue
+    // counter the bottleneck of both kernels.)
+    // The state of the wave's live paths is STREAMED: round r reads slots [0, n) of its region in buffer r & 1 and
+    // writes the paths that stay alive to slots [0, n') of the other buffer.  Live paths are therefore always dense in
+    // memory -- late rounds, when a few per cent of the paths are left, read full cache lines instead of one 8-byte
+    // field per sector -- and no list of live path ids is needed.
     const uint32_t sq = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     uint32_t* const my_ctr = A.ctr + (size_t)sq * CT_STRIDE;
     uint32_t n_live_local = 0, n_items_local = 0;  // wave-uniform
-    // round 0: sub-list sq is the wave-sized blocks g = k * nq + sq of the identity list
+    // round 0: the wave's paths are the 64-path blocks k * nq + sq (sample, tile), dealt round-robin for balance
     const uint32_t blocks_total = (A.np + 63u) / 64u;
     const uint32_t n_in_list = ROUND0 ? ((blocks_total + A.nq - 1u - sq) / A.nq) * 64u : my_ctr[round & 1u];
-    const uint32_t* __restrict__ live_in = A.live[round & 1u] + (size_t)sq * A.cap_l;
-    uint32_t* __restrict__ live_out = A.live[(round + 1u) & 1u] + (size_t)sq * A.cap_l;
-    double* const D = A.D;
-    uint32_t* const U = A.U;
+    const double* __restrict__ const Din = A.D[round & 1u];
+    const uint32_t* __restrict__ const Uin = A.U[round & 1u];
+    double* __restrict__ const Dout = A.D[(round + 1u) & 1u];
+    uint32_t* __restrict__ const Uout = A.U[(round + 1u) & 1u];
     const int K = (int)A.max_bounces;
     const uint32_t nL = S.n_lights;
     Counters cnt;
@@ -147,24 +155,16 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
     for (uint32_t k = 0; k * 64u < n_in_list; ++k) {  // wave-uniform trip count
         const uint32_t idx = k * 64u + lane;
         bool valid = idx < n_in_list;
-        uint32_t p = 0;
-        if (ROUND0) {
-            p = sq * A.cap_l + k * 64u + lane;            // storage slot: the wave's paths are contiguous in memory
-            valid = (k * A.nq + sq) < blocks_total;       // logical block (sample, tile), dealt round-robin for balance
-            if (!valid) p = sq * A.cap_l;
-        } else if (valid) {
-            p = live_in[idx];
-        }
-        auto ldD = [&](int f) -> double { return D[at64(PF_COUNT, f, p)]; };
-        auto stD = [&](int f, double v) { D[at64(PF_COUNT, f, p)] = v; };
+        const uint32_t p = sq * A.cap_l + (valid ? idx : 0u);  // slot read this round
+        if (ROUND0) valid = (k * A.nq + sq) < blocks_total;
+        auto ldD = [&](int f) -> double { return Din[at64(PF_COUNT, f, p)]; };
         auto ldD3 = [&](int f) -> V3 { return mk(ldD(f), ldD(f + 1), ldD(f + 2)); };
-        auto stD3 = [&](int f, V3 v) { stD(f, v.x); stD(f + 1, v.y); stD(f + 2, v.z); };
-        auto ldU = [&](int f) -> uint32_t { return U[at64(PU_COUNT, f, p)]; };
-        auto stU = [&](int f, uint32_t v) { U[at64(PU_COUNT, f, p)] = v; };
+        auto ldU = [&](int f) -> uint32_t { return Uin[at64(PU_COUNT, f, p)]; };
 
-        // path -> sample, pixel
-        const uint32_t blk = ((p % A.cap_l) >> 6) * A.nq + p / A.cap_l;  // logical block of the slot
-        const uint32_t s = blk / A.n_tiles, tile = blk - s * A.n_tiles, in = p & 63u;
+        // home slot -> sample, pixel (the slot the path had in round 0; block b lives at (b % nq) * cap_l + (b / nq) * 64)
+        const uint32_t home = (ROUND0 || !valid) ? p : ldU(PU_HOME);
+        const uint32_t blk = ((home % A.cap_l) >> 6) * A.nq + home / A.cap_l;
+        const uint32_t s = blk / A.n_tiles, tile = blk - s * A.n_tiles, in = home & 63u;
         const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
         const uint32_t lyc = (tile / A.tiles_x) * 8u + (in >> 3);
         if (ROUND0 && !(x < A.W && lyc < A.rows)) valid = false;  // padding of a ragged tile: never alive
@@ -172,12 +172,13 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         const uint32_t yy = A.row_begin + ly * A.row_stride;
         const uint32_t pixel = x + A.W * yy;  // main.rs:160-161,177
 
-        // what this round produces
-        bool cont = false;                      // the path stays alive
+        // what this round produces, and the state that travels on
+        bool cont = false;  // the path stays alive
         bool go0 = false, go1 = false, go2 = false;
-        V3 o = mk(0, 0, 0), dir0 = mk(0, 0, 1), nn = mk(0, 0, 1);
-        uint32_t fl = 0, bounce = 0, li = 0, n_sh = 0;
-        uint32_t h_obj = kNoId, h_mat = 0, h_kp = 0, h_tri = kNoId;
+        V3 o = mk(0, 0, 0), dir0 = mk(0, 0, 1), nn = mk(0, 0, 1), col = mk(0, 0, 0), diff = mk(0, 0, 0);
+        double att = 1.0, ba0 = 0.0, sba0 = 0.0, sba1 = 0.0, held_t = 0.0;
+        uint32_t fl = 0, bounce = 0, li = 0, n_sh = 0, mat = 0, held_tri = kNoId, held_m = kNoId;
+        uint32_t h_obj = kNoId, h_mat = 0, h_kp = 0, h_tri = kNoId;  // slot 0's analytic hit (travels on while its result is pending)
         double best0 = 0.0;
         bool found0 = false;
 
@@ -194,28 +195,30 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 const double v = ((double)yy + yo - (double)A.H * 0.5) / (double)A.H;  // main.rs:166
                 dir0 = normalize(ld3(S.cam_fwd) * S.cam_zoom + ld3(S.cam_up) * v + ld3(S.cam_right) * u);  // camera.rs:47
                 o = ld3(S.cam_pos);
-                stD3(PF_COL, mk(0, 0, 0));
-                stD(PF_ATT, 1.0);
-                stD3(PF_O, o);
                 go0 = true;
                 cont = true;
                 if (STATS) cnt.v[C_CAM]++;
             } else {
-                // ---- every load this round can need, issued before anything is decided: the kernel moves ~1 KB per
+                // ---- every load this round can need, issued before anything is decided: the kernel moves ~0.5 KB per
                 //      path and is bound by memory latency, not by the few bytes a path in another state would skip
                 fl = ldU(PU_FL);
                 const uint32_t ctr = ldU(PU_CTR);
                 o = ldD3(PF_O);
-                const double l_ba0 = ldD(PF_BA0);
-                const uint32_t l_hobj = ldU(PU_HOBJ), l_hmat = ldU(PU_HMAT), l_hkp = ldU(PU_HKP), l_mat = ldU(PU_MAT);
-                const FrontResult l_r0 = A.res[at64(3, 0, p)], l_r1 = A.res[at64(3, 1, p)], l_r2 = A.res[at64(3, 2, p)];
-                const uint32_t l_rm0 = l_r0.model, l_rm1 = l_r1.model, l_rm2 = l_r2.model, l_rtri0 = l_r0.tri;
-                const double l_rt0 = l_r0.t, l_rt1 = l_r1.t, l_rt2 = l_r2.t;
-                const double l_sba0 = ldD(PF_SBA), l_sba1 = ldD(PF_SBA + 1);
-                const V3 l_nrm = ldD3(PF_NRM), l_d0 = ldD3(PF_D0), l_col = ldD3(PF_COL);
-                const double l_att = ldD(PF_ATT);
+                ba0 = ldD(PF_BA0);
+                h_obj = ldU(PU_HOBJ); h_mat = ldU(PU_HMAT); h_kp = ldU(PU_HKP);
+                mat = ldU(PU_MAT);
+                FrontResult r0 = A.res[at64(3, 0, p)];
+                const FrontResult l_r1 = A.res[at64(3, 1, p)], l_r2 = A.res[at64(3, 2, p)];
+                held_t = ldD(PF_HELD); held_tri = ldU(PU_HTRI); held_m = ldU(PU_HM);
+                sba0 = ldD(PF_SBA); sba1 = ldD(PF_SBA + 1);
+                nn = ldD3(PF_NRM);
+                dir0 = ldD3(PF_D0);
+                col = ldD3(PF_COL);
+                att = ldD(PF_ATT);
+                if (nL > 2u) diff = ldD3(PF_DIFF);
                 bounce = ctr & 0xFFFFu;
                 li = ctr >> 16;
+                if (fl & FB_HELD) { r0.t = held_t; r0.tri = held_tri; r0.model = held_m; }  // slot 0's answer came in an earlier round
                 // ---- 0. decisions
                 const bool a_v = (fl & FB_HASV) != 0u;
                 const uint32_t n_in = a_v ? ((fl >> FB_NSH_SHIFT) & 3u) : 0u;  // shadow results to consume
@@ -223,24 +226,27 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 const bool a_fin = a_v && !a_more;                              // the vertex is complete (main.rs:107-125)
                 const bool a_end = a_fin && (int)bounce + 1 >= K;               // ... and it was the last one allowed
                 const bool b_take = !a_more && !a_end;                          // the path query's result is due
+                if (a_more && (fl & FB_TQ0)) {  // keep slot 0's answer: the trace kernel reuses the result slots next round
+                    held_t = r0.t; held_tri = r0.tri; held_m = r0.model;
+                    fl |= FB_HELD;
+                }
                 // ---- 1. the path query: analytic hit, then the model hit the trace kernel found (core.rs:75-83)
                 if (b_take) {
-                    best0 = l_ba0;
+                    best0 = ba0;
                     found0 = (fl & FB_FOUND0) != 0u;
-                    h_obj = l_hobj; h_mat = l_hmat; h_kp = l_hkp;
-                    if ((fl & FB_TQ0) && l_rm0 != kNoId) {
-                        const uint32_t m = l_rm0;
-                        const double t = l_rt0;
+                    if ((fl & FB_TQ0) && r0.model != kNoId) {
+                        const uint32_t m = r0.model;
+                        const double t = r0.t;
                         const uint32_t mobj = S.models[m].obj;
                         if (!(t <= kEps) && (t < best0 || (found0 && t == best0 && mobj < h_obj))) {
                             best0 = t; found0 = true;
-                            h_obj = mobj; h_mat = S.models[m].mat; h_kp = (2u << 30) | m; h_tri = l_rtri0;
+                            h_obj = mobj; h_mat = S.models[m].mat; h_kp = (2u << 30) | m; h_tri = r0.tri;
                         }
                     }
                 }
                 const bool b_hit = b_take && found0, b_miss = b_take && !found0;
                 const bool end_sample = a_end || b_miss;
-                const uint32_t mat_old = a_fin ? l_mat : 0u;
+                const uint32_t mat_old = a_fin ? mat : 0u;
                 const bool metal_old = S.materials[(size_t)mat_old * 4 + 3] != 0.0;
                 const uint32_t mat_new = b_hit ? h_mat : mat_old;
                 const bool metal_new = S.materials[(size_t)mat_new * 4 + 3] != 0.0;
@@ -254,9 +260,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 // ---- 2. shadow results of the pending vertex, in light order (main.rs:80-104); o == P.  The ray towards
                 //      the light and what it would add are recomputed from (P, n, light) -- the same expressions that
                 //      produced the ray -- rather than carried through memory.
-                V3 diff = mk(0, 0, 0);
                 if (n_in > 0u) {
-                    if (li > 0u) diff = ldD3(PF_DIFF);
+                    if (li == 0u) diff = mk(0, 0, 0);
                     auto shade = [&](const uint32_t j, const double sba, const uint32_t rm, const double rt) __attribute__((always_inline)) {
                         if (j < n_in && (fl & (FB_C1 << j))) {  // a query that cannot contribute is not looked at
                             const double* L = S.lights + (size_t)(li + j) * 8;
@@ -269,22 +274,20 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                             bool occluded = false;
                             if (found) occluded = sqdist(ray_at(o, dir, best), o) <= dl2;
                             if (!occluded) {
-                                const double eff = dot(dir, l_nrm);  // > 0.001, or FB_C would not be set
+                                const double eff = dot(dir, nn);  // > 0.001, or FB_C would not be set
                                 const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
                                 const double decay = 1.0 / dd;
                                 diff = diff + ld3(L + 3) * decay * eff;
                             }
                         }
                     };
-                    shade(0u, l_sba0, l_rm1, l_rt1);
-                    shade(1u, l_sba1, l_rm2, l_rt2);
+                    shade(0u, sba0, l_r1.model, l_r1.t);
+                    shade(1u, sba1, l_r2.model, l_r2.t);
                     li += n_in;
-                    if (a_more) stD3(PF_DIFF, diff);
+                } else if (a_fin) {
+                    diff = mk(0, 0, 0);  // a vertex without lights
                 }
                 // ---- 3. end of the light loop: the surface's colour, attenuation (main.rs:107-125)
-                V3 col = mk(0, 0, 0);
-                double att = 0.0;
-                if (a_fin || b_miss) { col = l_col; att = l_att; }
                 if (a_fin) {
                     const double* mp = S.materials + (size_t)mat_old * 4;
                     col = col + ld3(mp) * att * (diff * (metal_old ? 0.2 : 0.9));
@@ -299,11 +302,13 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     if (out_tri) out_tri[oi] = found0 ? h_tri : kNoId;
                 }
                 if (b_miss) col = col + mk(1, 1, 1) * att;  // main.rs:127
-                if (a_fin || b_miss) { stD3(PF_COL, col); stD(PF_ATT, att); }
+                if (end_sample) {  // the sample's colour, where the resolve kernel looks for it
+                    A.fin[at64(3, 0, home)] = col.x; A.fin[at64(3, 1, home)] = col.y; A.fin[at64(3, 2, home)] = col.z;
+                }
                 bool norm0 = false;
                 if (b_hit) {
                     // surface point and shading normal (core.rs:89,169-177,195,209; main.rs:68-73)
-                    const V3 d = l_d0;
+                    const V3 d = dir0;
                     const V3 P = ray_at(o, d, best0);
                     const uint32_t kind = h_kp >> 30, prim = h_kp & 0x3FFFFFFFu;
                     V3 raw;
@@ -321,14 +326,10 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     const V3 dif = nn + rnd;
                     dir0 = sel3(metal_new, refl, dif);
                     norm0 = !metal_new;
-                    stU(PU_MAT, mat_new);
+                    mat = mat_new;
                     o = P;  // the shadow rays start here and so does the bounce (main.rs:82,121)
-                    stD3(PF_O, o);
-                    stD3(PF_NRM, nn);
                     li = 0;
                     fl |= FB_HASV;
-                } else if (a_more) {
-                    nn = l_nrm;
                 }
                 // ---- 5. the new queries
                 go0 = b_hit && (int)bounce + 1 < K;
@@ -344,9 +345,16 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 if (STATS) cnt.v[C_SHADOW] += n_sh;
                 cont = !end_sample;
                 // flags that describe the queries are rebuilt below; slot 0's stay while its result is still pending
-                fl &= a_more ? (FB_HASV | FB_FOUND0 | FB_TQ0) : FB_HASV;
+                fl &= a_more ? (FB_HASV | FB_FOUND0 | FB_TQ0 | FB_HELD) : FB_HASV;
             }
         }
+        // ---- the slot the path moves to (dense, in the other buffer)
+        const unsigned long long alive = __ballot(valid && cont);
+        const uint32_t p_out = sq * A.cap_l + n_live_local + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull));
+        n_live_local += (uint32_t)__popcll(alive);
+        auto stD = [&](int f, double v) { Dout[at64(PF_COUNT, f, p_out)] = v; };
+        auto stD3 = [&](int f, V3 v) { stD(f, v.x); stD(f + 1, v.y); stD(f + 2, v.z); };
+        auto stU = [&](int f, uint32_t v) { Uout[at64(PU_COUNT, f, p_out)] = v; };
 
         // ---- a query: analytic primitives (core.rs:183-210), slab test and DDA set-up of the first model whose box
         //      the ray meets (box3D.rs:64-93, core.rs:95-125); that model and the following ones are the trace kernel's
@@ -390,11 +398,12 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     consider(t, S.pl_ids[i * 2 + 1], S.pl_ids[i * 2], (1u << 30) | i);
                 }
                 if (j == 0u) {
-                    stD3(PF_D0, dir);
-                    stD(PF_BA0, best);
-                    stU(PU_HOBJ, b_obj); stU(PU_HMAT, b_mat); stU(PU_HKP, b_kp);
+                    ba0 = best;
+                    h_obj = b_obj; h_mat = b_mat; h_kp = b_kp;
+                } else if (j == 1u) {
+                    sba0 = best;
                 } else {
-                    stD(PF_SBA + (int)j - 1, best);
+                    sba1 = best;
                 }
                 if (found) fl |= FB_FOUND0 << j;
                 {
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     I[at64(IT_DCOUNT, IT_TM + 0, it)] = tmx; I[at64(IT_DCOUNT, IT_TM + 1, it)] = tmy; I[at64(IT_DCOUNT, IT_TM + 2, it)] = tmz;
                     I[at64(IT_DCOUNT, IT_TD + 0, it)] = tdx; I[at64(IT_DCOUNT, IT_TD + 1, it)] = tdy; I[at64(IT_DCOUNT, IT_TD + 2, it)] = tdz;
                     A.itU[at64(IU_COUNT, IU_CELL, it)] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
-                    A.itU[at64(IU_COUNT, IU_Q, it)] = (p << 2) | j;  // query id: path and slot
+                    A.itU[at64(IU_COUNT, IU_Q, it)] = (p_out << 2) | j;  // query id: the path's next slot, and the query slot
                     A.itU[at64(IU_COUNT, IU_M, it)] = mword;
                 }
             }
@@ -466,14 +475,15 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
             shadow(0u, go1);
             shadow(1u, go2);
         }
-        if (valid && cont) {
+        if (valid && cont) {  // the state moves on
+            stD3(PF_COL, col); stD(PF_ATT, att);
+            stD3(PF_O, o); stD3(PF_D0, dir0); stD3(PF_NRM, nn);
+            stD(PF_BA0, ba0); stD(PF_SBA, sba0); stD(PF_SBA + 1, sba1); stD(PF_HELD, held_t);
+            if (nL > 2u) stD3(PF_DIFF, diff);
             stU(PU_FL, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT));
             stU(PU_CTR, bounce | (li << 16));
-        }
-        {
-            const unsigned long long alive = __ballot(valid && cont);
-            if (valid && cont) live_out[n_live_local + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull))] = p;
-            n_live_local += (uint32_t)__popcll(alive);
+            stU(PU_HOBJ, h_obj); stU(PU_HMAT, h_mat); stU(PU_HKP, h_kp); stU(PU_MAT, mat);
+            stU(PU_HOME, home); stU(PU_HTRI, held_tri); stU(PU_HM, held_m);
         }
     }
     if (lane == 0) {
@@ -690,7 +700,8 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         fl &= ~F_FRESH;
                         if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {  // core.rs:129-134
                             if (STATS) cnt.v[C_CELLS]++;
-                            const uint32_t cell = ((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix;
+                            // (coordinates and n are below 2^10: 24-bit multiplies are full rate, 32-bit ones a quarter)
+                            const uint32_t cell = __umul24(__umul24((uint32_t)iz, n) + (uint32_t)iy, n) + (uint32_t)ix;
                             uint32_t word;
                             // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one
                             // block, the wait before the bit test would also wait for the previous step's cell_start loads)
@@ -745,7 +756,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         const unsigned long long wants = __ballot((uint32_t)j < cntw);
                         if (j >= 2 && !wants) continue;
                         if (STATS) { dg_slots++; dg_slot_lanes += (uint64_t)__popcll(wants); }
-                        const gptr<double> tp = cell_rec + (size_t)ti[j] * 10;
+                        const gptr<double> tp = cell_rec + (uint32_t)(ti[j] * 10u);  // fewer than 2^26 entries (kMaxListEntries)
                         const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
                         ti[j] = (uint32_t)__double_as_longlong(tp[9]);  // the record ends with the triangle's index
                         const V3 pv = cross(d, e2);
@@ -825,7 +836,7 @@ __global__ __launch_bounds__(kBlock) void front_resolve_kernel(FrontArgs A, doub
     for (uint32_t s = 0; s < A.spp; ++s) {
         const uint32_t blk = s * A.n_tiles + tile;
         const size_t p = (size_t)(blk % A.nq) * A.cap_l + (size_t)(blk / A.nq) * 64u + in;  // the slot the shade kernel used
-        px = px + mk(A.D[at64(PF_COUNT, PF_COL + 0, p)], A.D[at64(PF_COUNT, PF_COL + 1, p)], A.D[at64(PF_COUNT, PF_COL + 2, p)]) / n_spp;
+        px = px + mk(A.fin[at64(3, 0, p)], A.fin[at64(3, 1, p)], A.fin[at64(3, 2, p)]) / n_spp;
     }
     const size_t oi = (size_t)(A.row0 + lyc) * A.W + x;
     out_rgb[oi * 3] = px.x;
