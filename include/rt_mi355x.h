@@ -121,7 +121,8 @@ const char* rtm_version(void);
 /* Scheduling knobs of the device path (no effect on results; no counterpart in the reference).  Keys:
  *   "front_max_paths"  sample paths kept in flight per band of rows (workspace: ~700 B each; default 32 Mi),
  *   "front_cull"       1 (default): shadow rays whose light is behind the surface (main.rs:96 fails) are not traced,
- *   "front_refill"     idle lanes per wave at which the trace kernel fetches new rays (default 16).
+ *   "front_refill"     idle lanes per wave at which the trace kernel fetches new rays (default 16),
+ *   "front_streams"    chunks of a frame in flight at once on internal streams (1..4, default 2).
  * Returns RTM_ERR_INVALID for an unknown key or a value out of range.  The same knobs are read from the
  * environment (RTM_FRONT_MAX_PATHS, ...) by rtm_init. */
 int rtm_set_tuning(const char* key, long long value);

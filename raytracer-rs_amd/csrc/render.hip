@@ -35,6 +35,10 @@ static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile 
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
 static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); env RTM_KERNEL=wave|front
+constexpr int kFrontStreamsMax = 4;
+static uint32_t g_front_streams = 2;  // chunks of a frame in flight at once; env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
+static hipStream_t g_front_stream[kFrontStreamsMax] = {};
+static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
 static bool g_front_debug_rounds = false;
 static uint32_t g_front_refill = 16, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
 struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
@@ -277,6 +281,14 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
     g_front_debug_rounds = std::getenv("RTM_FRONT_DEBUG_ROUNDS") != nullptr;
+    if (const char* e = std::getenv("RTM_FRONT_STREAMS")) g_front_streams = (uint32_t)std::max(1, std::min(kFrontStreamsMax, std::atoi(e)));
+    if (!g_front_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&g_front_fork, hipEventDisableTiming));
+        for (int i = 0; i < kFrontStreamsMax; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&g_front_stream[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&g_front_join[i], hipEventDisableTiming));
+        }
+    }
     if (const char* e = std::getenv("RTM_FRONT_CULL")) g_front_cull = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(64ll, std::atoll(e));
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
@@ -291,12 +303,21 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_max_paths" && value >= 64 && value <= (1ll << 31)) { g_front_max_paths = (size_t)value; return RTM_OK; }
     if (k == "front_cull" && (value == 0 || value == 1)) { g_front_cull = (uint32_t)value; return RTM_OK; }
     if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
+    if (k == "front_streams" && value >= 1 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
     return rtm_internal_fail(RTM_ERR_INVALID, "unknown tuning key or value out of range: " + k);
 }
 
 int rtm_shutdown(void) {
     if (g_work_counter) (void)hipFree(g_work_counter);
     g_work_counter = nullptr;
+    if (g_front_fork) {
+        (void)hipEventDestroy(g_front_fork);
+        g_front_fork = nullptr;
+        for (int i = 0; i < kFrontStreamsMax; ++i) {
+            (void)hipStreamDestroy(g_front_stream[i]);
+            (void)hipEventDestroy(g_front_join[i]);
+        }
+    }
     if (g_front_ws.base) (void)hipFree(g_front_ws.base);
     g_front_ws.base = nullptr;
     g_front_ws.bytes = 0;
@@ -472,24 +493,27 @@ __global__ void front_sum_items_kernel(const uint32_t* ctr, uint32_t nq, unsigne
 int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, uint32_t occ_words, double* d_rgb, uint32_t* d_obj,
                  uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof = nullptr) {
     const bool stats = d_cnt != nullptr;
-    auto mark = [&](int kind, bool end) {  // event before / after a launch (profile runs only)
+    auto mark = [&](int kind, bool end, hipStream_t on) {  // event before / after a launch (profile runs only)
         if (!prof || prof->keep_cull) return;
         if (!end) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
             prof->ev[kind].push_back({a, b});
-            (void)hipEventRecord(a, stream);
+            (void)hipEventRecord(a, on);
         } else {
-            (void)hipEventRecord(prof->ev[kind].back().second, stream);
+            (void)hipEventRecord(prof->ev[kind].back().second, on);
         }
     };
     const uint32_t tiles_x = (p->width + 7) / 8;
     const size_t band_paths = (size_t)tiles_x * 64u * p->spp;  // paths of one 8-row band
     if (band_paths > 0x3FFFFFFFu / 3u) return rtm_internal_fail(RTM_ERR_INVALID, "width x spp too large for one band of paths");
     const uint32_t bands_total = (n_rows + 7) / 8;
-    uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / band_paths);
-    bands_per_chunk = std::min(bands_per_chunk, bands_total);
+    // The frame is cut into chunks of whole 8-row bands; chunk c runs on internal stream c % n_conc with its own work space,
+    // so the late rounds of one chunk (few paths alive: launch- and latency-bound) overlap the heavy rounds of another.
+    const uint32_t n_conc = std::max<uint32_t>(1, std::min<uint32_t>({g_front_streams, (uint32_t)kFrontStreamsMax, bands_total}));
+    uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / n_conc / band_paths);
+    bands_per_chunk = std::min(bands_per_chunk, (bands_total + n_conc - 1) / n_conc);
     const size_t np_max = band_paths * bands_per_chunk;
     if (np_max + (size_t)64 * 64 * 1024 >= (1ull << 30)) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
     // sub-queues (rt_front.h): the shade grid is a multiple of nq waves
@@ -506,14 +530,21 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const size_t o_fin = take(slots_max * 3 * 8), o_res = take(slots_max * 3 * sizeof(rtf::FrontResult));
     const size_t o_itD = take(items_max * rtf::IT_DCOUNT * 8), o_itU = take(items_max * rtf::IU_COUNT * 4);
     const size_t o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
-    if (off > g_front_ws.bytes) {
+    const size_t ws_one = (off + 4095) & ~(size_t)4095;
+    if (ws_one * n_conc > g_front_ws.bytes) {
         if (g_front_ws.base) HIP_TRY(hipFree(g_front_ws.base));
         g_front_ws.base = nullptr;
         g_front_ws.bytes = 0;
-        HIP_TRY(hipMalloc((void**)&g_front_ws.base, off));
-        g_front_ws.bytes = off;
+        HIP_TRY(hipMalloc((void**)&g_front_ws.base, ws_one * n_conc));
+        g_front_ws.bytes = ws_one * n_conc;
     }
-    char* const B = g_front_ws.base;
+    // fork: the internal streams start after whatever the caller queued on `stream`
+    hipStream_t lanes[kFrontStreamsMax];
+    for (uint32_t i = 0; i < n_conc; ++i) lanes[i] = n_conc == 1 ? stream : g_front_stream[i];
+    if (n_conc > 1) {
+        HIP_TRY(hipEventRecord(g_front_fork, stream));
+        for (uint32_t i = 0; i < n_conc; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i], g_front_fork, 0));
+    }
     const uint32_t B_rounds = std::max<uint32_t>(1, (sd->view.n_lights + 1) / 2);
     const uint32_t rounds = 2 + std::max<uint32_t>(p->max_bounces, 1) * B_rounds;
     const dim3 block(256);
@@ -522,8 +553,11 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     uint32_t occ_total = 0;
     for (uint32_t w : sd->occ_words) occ_total += w;
     const bool all_lds = occ_total == occ_words;  // every bitmap is staged in LDS
-    for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk) {
+    uint32_t chunk = 0;
+    for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk, ++chunk) {
         const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
+        hipStream_t stream = lanes[chunk % n_conc];                            // (shadows the caller's stream inside the loop)
+        char* const B = g_front_ws.base + (size_t)(chunk % n_conc) * ws_one;
         rtf::FrontArgs A{};
         A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_bounces = p->max_bounces; A.seed = p->seed;
         A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
@@ -539,7 +573,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.ctr = (uint32_t*)(B + o_ctr);
         const uint32_t shade_wgs0 = shade_wgs;
         for (uint32_t r = 0; r < rounds; ++r) {
-            mark(0, false);
+            mark(0, false, stream);
             if (r == 0) {
                 if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
                 else hipLaunchKernelGGL((rtf::front_shade_kernel<false, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
@@ -547,11 +581,11 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
                 else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
             }
-            mark(0, true);
+            mark(0, true, stream);
             if (prof && prof->d_items && !prof->keep_cull)
                 hipLaunchKernelGGL(front_sum_items_kernel, dim3(32), dim3(256), 0, stream, A.ctr, nq, prof->d_items);
             if (r + 1 < rounds) {  // the last round only finalises
-                mark(1, false);
+                mark(1, false, stream);
                 const size_t lds = (size_t)occ_words * 4;
                 if (stats) {
                     if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<true, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
@@ -560,7 +594,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<false, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
                     else hipLaunchKernelGGL((rtf::front_trace_kernel<false, false>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
                 }
-                mark(1, true);
+                mark(1, true, stream);
             }
             HIP_TRY(hipGetLastError());
             if (g_front_debug_rounds) {  // RTM_FRONT_DEBUG_ROUNDS=1: list lengths after every round (synchronises; diagnostics only)
@@ -578,10 +612,16 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                              (unsigned long long)live, live_max, nq, (unsigned long long)items, items_max);
             }
         }
-        mark(2, false);
+        mark(2, false, stream);
         hipLaunchKernelGGL(rtf::front_resolve_kernel, dim3((A.npix + 255) / 256), block, 0, stream, A, d_rgb);
-        mark(2, true);
+        mark(2, true, stream);
         HIP_TRY(hipGetLastError());
+    }
+    if (n_conc > 1) {  // join: the caller's stream continues after every internal stream
+        for (uint32_t i = 0; i < n_conc; ++i) {
+            HIP_TRY(hipEventRecord(g_front_join[i], lanes[i]));
+            HIP_TRY(hipStreamWaitEvent(stream, g_front_join[i], 0));
+        }
     }
     return RTM_OK;
 }

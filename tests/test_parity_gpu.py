@@ -111,7 +111,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
     ref = oracle_scene("suzanne").render(spp=3, seed=4, width=203, height=77)
     try:
         for key, value in (("front_max_paths", 64), ("front_max_paths", 26 * 64 * 3 * 4), ("front_cull", 0), ("front_refill", 1),
-                           ("front_refill", 64)):
+                           ("front_refill", 64), ("front_streams", 1), ("front_streams", 4)):
             rtm_gpu.set_tuning(key, value)
             g = s.render(spp=3, seed=4, width=203, height=77, stats=True)
             assert_frames_match(g, ref, f"suzanne {key}={value}")
@@ -122,6 +122,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("front_max_paths", 32 << 20)
         rtm_gpu.set_tuning("front_cull", 1)
         rtm_gpu.set_tuning("front_refill", 16)
+        rtm_gpu.set_tuning("front_streams", 2)
     with pytest.raises(rtm_gpu.RtmError):
         rtm_gpu.set_tuning("no_such_knob", 1)
 
