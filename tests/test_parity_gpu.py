@@ -127,6 +127,27 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("no_such_knob", 1)
 
 
+def test_profile_entry_point(rtm_gpu, rtm_scene):
+    """rtm_profile_render_device (bench.py's roofline source): kernel times add up, and the work it reports is the
+    reference's work minus what the product path provably skips (culled shadow rays, entries already tested)."""
+    import torch
+    s = rtm_scene("bunny")
+    w = h = 200
+    p = rtm_gpu.make_params(w, h, spp=4, seed=3)
+    rgb = torch.empty(h, w, 3, dtype=torch.float64, device="cuda")
+    pr = s.profile_render_device(p, rgb.data_ptr())
+    ref = s.render(spp=4, seed=3, width=w, height=h, stats=True)
+    assert np.array_equal(rgb.cpu().numpy(), ref["rgb"])
+    c = ref["counters"]
+    assert pr["rays_total"] == c["rays_camera"] + c["rays_bounce"] + c["rays_shadow"]
+    assert 0 < pr["traced_rays"] <= c["bbox_tests"]
+    assert 0 < pr["tri_tests"] <= c["tri_tests"] and 0 < pr["cells_visited"] <= c["cells_visited"]
+    assert pr["trace_launches"] >= 1 and pr["shade_launches"] >= 2
+    assert pr["trace_ms"] > 0 and abs(pr["total_ms"] - (pr["shade_ms"] + pr["trace_ms"] + pr["resolve_ms"])) < 1e-9
+    pw = s.profile_render_device(rtm_gpu.make_params(w, h, spp=4, seed=3, kernel_wave=True), rgb.data_ptr())
+    assert pw["shade_launches"] == 0 and pw["tri_tests"] == c["tri_tests"]
+
+
 def test_zero_jitter_known_answer(rtm_gpu, rtm_scene):
     """Hand-derived KAT through the C ABI (see tests/test_oracle_kat.py): centre pixel hits the sphere, corner the plane."""
     g = rtm_scene("simple_sphere").render(spp=1, zero_jitter=True)
