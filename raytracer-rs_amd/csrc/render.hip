@@ -450,6 +450,18 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
                 }
             }
             if ((rc = upload(sd, info, &D.cell_info))) return fail(rc);
+            // ... and the same knowledge as bitmaps for the walk: arriving along direction a, a cell whose entries were all
+            // tested one step earlier is as good as empty
+            const size_t words = occ.size();
+            std::vector<uint32_t> occ7(words * 7, 0u);
+            for (size_t c = 0; c < n3; ++c) {
+                const uint32_t len = info[c * 8 + 1] - info[c * 8];
+                if (!len) continue;
+                for (int a = 0; a < 6; ++a)
+                    if (len > 32 || info[c * 8 + 2 + a] != 0u) occ7[(size_t)a * words + (c >> 5)] |= 1u << (c & 31);
+                occ7[6 * words + (c >> 5)] |= 1u << (c & 31);
+            }
+            if ((rc = upload(sd, occ7, &D.occupancy7))) return fail(rc);
         }
         if ((rc = upload(sd, start, &D.cell_start)) || (rc = upload(sd, idx, &D.tri_idx)) || (rc = upload(sd, pos, &D.tri_pos)) ||
             (rc = upload(sd, nrm, &D.tri_nrm)) || (rc = upload(sd, occ, &D.occupancy)))
@@ -474,6 +486,16 @@ bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
     // packed cell coordinates and model indices (rt_front.h); one 8-row band of paths must fit the workspace budget
     const uint64_t band_paths = (uint64_t)((p->width + 7) / 8) * 64u * p->spp;
     return sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && sd->max_list < rtf::kMaxListEntries && band_paths <= (64ull << 20);
+}
+
+// words of the direction bitmaps (seven per model) that fit the trace kernel's LDS budget, models in order
+uint32_t front_occ_words(const rtm_scene_dev* sd) {
+    uint32_t words = 0;
+    for (uint32_t w : sd->occ_words) {
+        if (words + 7u * w > (uint32_t)rtw::kOccLdsWordsMax) break;
+        words += 7u * w;
+    }
+    return words;
 }
 
 // One frame as bands of rows; per band: round 0 (camera rays), then shade/trace rounds until no path is alive.
@@ -552,7 +574,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t trace_wgs = (uint32_t)g_num_cus * (uint32_t)RTM_FRONT_OCC;
     uint32_t occ_total = 0;
     for (uint32_t w : sd->occ_words) occ_total += w;
-    const bool all_lds = occ_total == occ_words;  // every bitmap is staged in LDS
+    const bool all_lds = occ_total * 7u == occ_words;  // every bitmap is staged in LDS
     uint32_t chunk = 0;
     for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk, ++chunk) {
         const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
@@ -656,7 +678,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     int front_rc = RTM_OK;
     auto launch = [&](bool stats, unsigned long long* d_cnt) {
         if (front) {
-            front_rc = render_front(sd, p, n_rows, AW.occ_words, d_rgb, d_obj, d_tri, stats ? d_cnt : nullptr, stream);
+            front_rc = render_front(sd, p, n_rows, front_occ_words(sd), d_rgb, d_obj, d_tri, stats ? d_cnt : nullptr, stream);
             return front_rc == RTM_OK ? hipSuccess : hipErrorUnknown;
         }
         if (v1) {
@@ -754,11 +776,7 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
         out->traced_rays = st.bbox_tests;
         return RTM_OK;
     }
-    uint32_t occ_words = 0;
-    for (uint32_t w : sd->occ_words) {
-        if (occ_words + w > (uint32_t)rtw::kOccLdsWordsMax) break;
-        occ_words += w;
-    }
+    const uint32_t occ_words = front_occ_words(sd);
     unsigned long long* d_buf = nullptr;  // [0..31] counters of the counting run, [32] traced rays
     HIP_TRY(hipMalloc((void**)&d_buf, 40 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(d_buf, 0, 40 * sizeof(unsigned long long), stream));

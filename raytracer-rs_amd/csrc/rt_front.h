@@ -506,9 +506,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         uint32_t base = 0;
         for (uint32_t m = 0; m < S.n_models; ++m) {
             const uint32_t n = S.models[m].n;
-            const uint32_t words = (n * n * n + 31u) >> 5;
+            const uint32_t words = 7u * ((n * n * n + 31u) >> 5);  // seven bitmaps per model: one per arrival direction
             if (base + words > A.occ_words) break;
-            const gptr<uint32_t> src = as_global(S.models[m].occupancy);
+            const gptr<uint32_t> src = as_global(S.models[m].occupancy7);
             for (uint32_t i = tid; i < words; i += kBlock) occ_lds[base + i] = src[i];
             base += words;
         }
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         uint32_t occ_base = 0;  // LDS word offset of this model's bitmap, or 0xFFFFFFFF when it stayed in HBM
         for (uint32_t j = 0; j <= mm; ++j) {
             const uint32_t nj = S.models[j].n;
-            const uint32_t words = (nj * nj * nj + 31u) >> 5;
+            const uint32_t words = 7u * ((nj * nj * nj + 31u) >> 5);
             if (occ_base + words > A.occ_words) { occ_base = 0xFFFFFFFFu; break; }
             if (j < mm) occ_base += words;
         }
@@ -674,7 +674,8 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.n), M_obj = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.obj);
         const gptr<uint32_t> cell_info = as_global(M.cell_info);
         const gptr<double> cell_rec = as_global(M.cell_rec);
-        const gptr<uint32_t> occ_glb = as_global(M.occupancy);
+        const gptr<uint32_t> occ_glb = as_global(M.occupancy7);
+        const uint32_t occ_dir_words = (n * n * n + 31u) >> 5;  // words of one direction's bitmap
         const bool occ_in_lds = occ_base != 0xFFFFFFFFu;
         const bool last_model = mm + 1u >= S.n_models;
         for (;;) {
@@ -705,8 +706,11 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                             uint32_t word;
                             // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one
                             // block, the wait before the bit test would also wait for the previous step's cell_start loads)
-                            if (ALL_LDS || occ_in_lds) word = occ_lds[occ_base + (cell >> 5)];
-                            else word = occ_glb[cell >> 5];
+                            // the bitmap of the arrival direction: cells whose entries were all tested one step ago count as
+                            // empty (the counting build uses the plain occupancy, like the reference)
+                            const uint32_t wi = (A.cull ? arr : 6u) * occ_dir_words + (cell >> 5);
+                            if (ALL_LDS || occ_in_lds) word = occ_lds[occ_base + wi];
+                            else word = occ_glb[wi];
                             if ((word >> (cell & 31u)) & 1u) {  // non-empty: the list is [k, k_end), k < k_end
                                 // list range and the arrival mask: one 32-byte record (used by the next test phase)
                                 const gptr<uint32_t> ci = cell_info + (size_t)cell * 8;

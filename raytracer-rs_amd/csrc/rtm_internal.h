@@ -25,6 +25,8 @@ struct RtmDevModel {
     const double* tri_pos;       // n_tris x 9: v0 xyz, (v1-v0) xyz, (v2-v0) xyz  -- edges of model.rs:46-47 / :20-21
     const double* tri_nrm;       // n_tris x 9
     const uint32_t* occupancy;   // n^3 bits: cell non-empty
+    const uint32_t* occupancy7;  // seven bitmaps back to back: arrival directions -x,+x,-y,+y,-z,+z (bit = the cell has an entry that was
+                                 // not already tested in the neighbour the step came from), then the plain occupancy (entry cell)
     const uint32_t* cell_info;   // n^3 x 8: list start, list end, then six masks -- which of the (<= 32) entries are NOT also listed in the
                                  // neighbour cell a DDA step along -x,+x,-y,+y,-z,+z came from (rt_front.h)
     const double* cell_rec;      // n_tri_idx x 10, in list order: the tri_pos record of entry k, then its triangle index (as integer bits)
