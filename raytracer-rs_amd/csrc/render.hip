@@ -40,6 +40,7 @@ static uint32_t g_front_streams = 2;  // chunks of a frame in flight at once; en
 static hipStream_t g_front_stream[kFrontStreamsMax] = {};
 static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
 static bool g_front_debug_rounds = false;
+static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
 static uint32_t g_front_refill = 16, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
 struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
     char* base = nullptr;
@@ -279,6 +280,8 @@ int rtm_init(int device) {
     }
     if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : 2;
     if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_FRONT_CLAIM")) g_front_claim = (uint32_t)std::max(16, std::atoi(e));
+    if (const char* e = std::getenv("RTM_FRONT_STEAL")) g_front_steal = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
     g_front_debug_rounds = std::getenv("RTM_FRONT_DEBUG_ROUNDS") != nullptr;
     if (const char* e = std::getenv("RTM_FRONT_STREAMS")) g_front_streams = (uint32_t)std::max(1, std::min(kFrontStreamsMax, std::atoi(e)));
@@ -303,6 +306,8 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_max_paths" && value >= 64 && value <= (1ll << 31)) { g_front_max_paths = (size_t)value; return RTM_OK; }
     if (k == "front_cull" && (value == 0 || value == 1)) { g_front_cull = (uint32_t)value; return RTM_OK; }
     if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
+    if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
+    if (k == "front_steal" && value >= 0 && value <= 4096) { g_front_steal = (uint32_t)value; return RTM_OK; }
     if (k == "front_streams" && value >= 1 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
     return rtm_internal_fail(RTM_ERR_INVALID, "unknown tuning key or value out of range: " + k);
 }
@@ -585,8 +590,9 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
         A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
         A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
-        A.cull = (stats && !(prof && prof->keep_cull)) ? 0u : g_front_cull;
+        A.cull = (stats && !(prof && prof->keep_cull) && !std::getenv("RTM_DIAG_KEEP_CULL")) ? 0u : g_front_cull;
         A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
+        A.claim = g_front_claim; A.steal = g_front_steal;
         A.occ_words = occ_words;
         A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
         A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);
@@ -632,6 +638,19 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 }
                 std::fprintf(stderr, "[rtm front] round %u: live %llu (max %u per sub-list of %u), items %llu (max %u)\n", r,
                              (unsigned long long)live, live_max, nq, (unsigned long long)items, items_max);
+                if (stats) {  // trace diagnostics of this round (the counters are cumulative; the maximum is reset here)
+                    static unsigned long long prev[32];
+                    unsigned long long h2[32];
+                    HIP_TRY(hipMemcpy(h2, d_cnt, sizeof h2, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemset(d_cnt + 21, 0, 8));
+                    if (r == 0) std::memset(prev, 0, sizeof prev);
+                    auto dl = [&](int i) { return (double)(h2[i] - prev[i]); };
+                    std::fprintf(stderr, "[rtm front]   trace: slowest wave %llu ticks with %llu iterations, mean wave %.0f ticks; walk iters %.0f (%.1f lanes) test steps %.0f (%.1f lanes); of wave time: refill %.1f%% walk %.1f%% test %.1f%%\n",
+                                 h2[21] >> 24, h2[21] & 0xFFFFFFull, dl(22) > 0 ? dl(20) / dl(22) : 0.0, dl(11), dl(11) > 0 ? dl(12) / dl(11) : 0.0, dl(9),
+                                 dl(9) > 0 ? dl(10) / dl(9) : 0.0, 100.0 * dl(23) / dl(20), 100.0 * dl(24) / dl(20), 100.0 * dl(25) / dl(20));
+                    std::memcpy(prev, h2, sizeof prev);
+                    prev[21] = 0;
+                }
             }
         }
         mark(2, false, stream);
@@ -705,7 +724,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
         if (std::getenv("RTM_DIAG") && front && h[22])
             std::fprintf(stderr, "[rtm diag front] trace waves %llu: mean %.0f cycles, sum of per-launch max not tracked; max single wave %llu cycles; total wave-cycles %.3g: refill %.1f%% (%.0f/refill)  walk %.1f%% (%.0f/iter)  test %.1f%% (%.0f/step)\n",
-                         h[22], (double)h[20] / (double)h[22], h[21], (double)h[20], 100.0 * h[23] / (double)h[20], h[15] ? (double)h[23] / h[15] : 0.0,
+                         h[22], (double)h[20] / (double)h[22], h[21] >> 24, (double)h[20], 100.0 * h[23] / (double)h[20], h[15] ? (double)h[23] / h[15] : 0.0,
                          100.0 * h[24] / (double)h[20], h[11] ? (double)h[24] / h[11] : 0.0, 100.0 * h[25] / (double)h[20], h[9] ? (double)h[25] / h[9] : 0.0);
         if (std::getenv("RTM_DIAG") && front)
             std::fprintf(stderr, "[rtm diag front] test steps %llu (avg %.1f lanes)  walk iters %llu (avg %.1f lanes)  test slots %llu (avg %.1f lanes)  refills %llu (avg %.1f lanes)\n",

@@ -71,7 +71,8 @@ enum : int { IT_O = 0, IT_D = 3, IT_TM = 6, IT_TD = 9, IT_DCOUNT = 12 };
 enum : int { IU_CELL = 0, IU_Q = 1, IU_M = 2, IU_COUNT = 3 };
 enum : uint32_t { IM_SX = 1u << 16, IM_SY = 1u << 17, IM_SZ = 1u << 18 };
 // device counters, one set per sub-queue (each written by the one wave that owns the sub-queue)
-enum : int { CT_LIVE0 = 0, CT_LIVE1 = 1, CT_ITEMS = 2, CT_STRIDE = 4 };
+// (CT_CLAIM is the one word several waves touch: the trace kernel's waves claim runs of a sub-queue's items from it)
+enum : int { CT_LIVE0 = 0, CT_LIVE1 = 1, CT_ITEMS = 2, CT_CLAIM = 3, CT_STRIDE = 4 };
 
 struct __attribute__((aligned(16))) FrontResult {  // one 16-byte store per traced ray
     double t;
@@ -88,6 +89,7 @@ struct FrontArgs {
                                 // (sample, tile) x lane; block b is stored at slot (b % nq) * cap_l + (b / nq) * 64: wave b % nq owns it
     uint32_t cull;              // 1: shadow queries that cannot contribute (eff <= 0.001) are not traced
     uint32_t refill;            // trace kernel: fetch new items when at least this many lanes of a wave are idle
+    uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
     uint32_t t_test_frac, t_min_lanes;
     uint32_t occ_words;
     double* D[2];               // path state, streamed from one buffer to the other every round
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
     if (lane == 0) {
         my_ctr[(round + 1u) & 1u] = n_live_local;
         my_ctr[CT_ITEMS] = n_items_local;
+        my_ctr[CT_CLAIM] = 0u;
     }
     flush_counters<STATS>(cnt, out_cnt);
 }
@@ -519,14 +522,18 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
     const uint64_t dg_begin = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t dg_tr = 0, dg_tw = 0, dg_tt = 0, dg_t0 = 0;  // cycles in refill / walk / test (STATS)
-    // the wave's position in the queue: it owns sub-queues sq, sq + waves, sq + 2 waves, ... and reads each in order
+    // The wave's position in the queue.  Sub-queues sq, sq + waves, sq + 2 waves, ... are its own; their items are
+    // claimed A.claim at a time from the sub-queue's cursor (one atomic per claim, by lane 0), so that a wave whose own
+    // sub-queues are empty can take runs from up to A.steal sub-queues of other waves: rays differ in cost by an order
+    // of magnitude and the launch lasts as long as its slowest wave.  Every wave stops after a bounded number of
+    // failed claims; nothing waits on another wave.
     const uint32_t trace_waves = gridDim.x * (kBlock / 64);
-    uint32_t sq = blockIdx.x * (kBlock / 64) + (tid >> 6);
-    uint32_t pool_next = 0, pool_end = 0;  // unread items of the current sub-queue
-    if (sq < A.nq) {
-        pool_next = sq * A.cap_i;
-        pool_end = pool_next + A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
-    }
+    const uint32_t wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
+    uint32_t sq = wave_id, sq_items = 0, stolen = 0;
+    bool stealing = false;
+    uint32_t pool_next = 0, pool_end = 0;  // unread items of the current claim
+    if (sq < A.nq) sq_items = A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
+    uint32_t steal_max = sq_items >= A.claim ? A.steal : 0u;  // (short queues, late rounds: nothing worth taking)
     const gptr<double> I = as_global(A.itD);
     const gptr<uint32_t> IU = as_global(A.itU);
 
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     int ix = 0, iy = 0, iz = 0;
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
     uint32_t k = 0, k_end = 0, m_tri = 0;  // [k, k_end): the rest of the current cell's list, k = first entry of the 32-entry window
-    uint32_t wmask = 0, mw = 0, arr = 6;   // untested entries of the window; the cell's mask for the arrival direction arr
+    uint32_t wmask = 0, arr = 6;           // untested entries of the window; the direction the ray arrived from
     double m_t = 0.0;
     // per-ray flags, kept as bits of one VGPR: as separate bools they live in SGPR lane masks and every join of the
     // divergent control flow below costs a handful of scalar mask merges per flag (half of the kernel's instructions)
@@ -586,11 +593,27 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             for (;;) {
                 idle = __ballot(st == TS_IDLE);
                 if (!idle) break;
-                if (pool_next == pool_end) {  // next sub-queue of this wave
-                    sq += trace_waves;
-                    if (sq >= A.nq) { exhausted = true; break; }
-                    pool_next = sq * A.cap_i;
-                    pool_end = pool_next + A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
+                if (pool_next == pool_end) {  // the next run of items (wave-uniform)
+                    if (sq_items) {
+                        uint32_t at = 0;
+                        if (lane == 0) at = atomicAdd(A.ctr + (size_t)sq * CT_STRIDE + CT_CLAIM, A.claim);
+                        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                        if (at < sq_items) {
+                            pool_next = sq * A.cap_i + at;
+                            pool_end = sq * A.cap_i + min(at + A.claim, sq_items);
+                            continue;
+                        }
+                    }
+                    if (!stealing) {  // own sub-queues first
+                        sq += trace_waves;
+                        if (sq >= A.nq) stealing = true;
+                    }
+                    if (stealing) {
+                        if (stolen >= steal_max) { exhausted = true; break; }
+                        ++stolen;
+                        sq = (wave_id + stolen * 2731u) % A.nq;  // (an odd stride: different waves try different sub-queues)
+                    }
+                    sq_items = A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
                     continue;
                 }
                 const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -711,12 +734,11 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                             const uint32_t wi = (A.cull ? arr : 6u) * occ_dir_words + (cell >> 5);
                             if (ALL_LDS || occ_in_lds) word = occ_lds[occ_base + wi];
                             else word = occ_glb[wi];
-                            if ((word >> (cell & 31u)) & 1u) {  // non-empty: the list is [k, k_end), k < k_end
-                                // list range and the arrival mask: one 32-byte record (used by the next test phase)
-                                const gptr<uint32_t> ci = cell_info + (size_t)cell * 8;
-                                k = ci[0];
-                                k_end = ci[1];
-                                mw = ci[2 + (arr < 6u ? arr : 0u)];
+                            if ((word >> (cell & 31u)) & 1u) {  // non-empty
+                                // The cell's record is read by the next test phase, not here: a load into registers that
+                                // an earlier step's load may still be filling makes the compiler wait for all of them,
+                                // one memory latency in every walk iteration that opens a cell.
+                                k = cell;
                                 fl |= F_WINIT | F_OPEN;
                             }
                         } else {  // left the grid without a hit
@@ -734,6 +756,11 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
                     // the same side).  Entries are applied in list order (core.rs:140-142).
                     if (fl & F_WINIT) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
+                        // list range [k, k_end), k < k_end, and the arrival mask: one 32-byte record
+                        const gptr<uint32_t> ci = cell_info + (size_t)k * 8;
+                        const uint32_t mw = ci[2 + (arr < 6u ? arr : 0u)];
+                        k_end = ci[1];
+                        k = ci[0];
                         const uint32_t len = k_end - k;
                         const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
                         wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
@@ -812,7 +839,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     if (STATS && lane == 0) {
         const unsigned long long el = (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_begin);
         atomicAdd(out_cnt + 20, el);
-        atomicMax(out_cnt + 21, el);
+        { const unsigned long long its = dg_steps + dg_walks; atomicMax(out_cnt + 21, (el << 24) | (its > 0xFFFFFFull ? 0xFFFFFFull : its)); }
         atomicAdd(out_cnt + 22, 1ull);
         atomicAdd(out_cnt + 23, (unsigned long long)dg_tr);
         atomicAdd(out_cnt + 24, (unsigned long long)dg_tw);
