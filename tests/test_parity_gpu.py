@@ -106,12 +106,13 @@ def test_kernels_agree_at_n_spp(kernel, rtm_gpu, rtm_scene, oracle_scene):
 
 def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, oracle_scene):
     """The ray-front scheduling knobs (rtm_set_tuning): many small bands of rows, ragged last band, culling off,
-    eager and lazy refill -- same image, ids and counters."""
+    eager and lazy refill, stream count, claim size and stealing -- same image, ids and counters."""
     s = rtm_scene("suzanne")
     ref = oracle_scene("suzanne").render(spp=3, seed=4, width=203, height=77)
     try:
         for key, value in (("front_max_paths", 64), ("front_max_paths", 26 * 64 * 3 * 4), ("front_cull", 0), ("front_refill", 1),
-                           ("front_refill", 64), ("front_streams", 1), ("front_streams", 4)):
+                           ("front_refill", 64), ("front_streams", 1), ("front_streams", 4), ("front_claim", 16), ("front_steal", 512),
+                           ("front_steal", 0)):
             rtm_gpu.set_tuning(key, value)
             g = s.render(spp=3, seed=4, width=203, height=77, stats=True)
             assert_frames_match(g, ref, f"suzanne {key}={value}")
@@ -123,6 +124,8 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("front_cull", 1)
         rtm_gpu.set_tuning("front_refill", 16)
         rtm_gpu.set_tuning("front_streams", 2)
+        rtm_gpu.set_tuning("front_claim", 128)
+        rtm_gpu.set_tuning("front_steal", 8)
     with pytest.raises(rtm_gpu.RtmError):
         rtm_gpu.set_tuning("no_such_knob", 1)
 

@@ -26,3 +26,7 @@ j["bunny_1200x1200_20spp_n1"] = {"kernel": "rtf::front_trace_kernel<false, true>
     "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (profiles/r01_pmc_front), summed over the 11 trace launches of a frame and divided by 11; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads; uncalibrated for 8-16 B gathers, so an upper-side estimate); the shade kernel's traffic (path state and ray queues) is listed beside it"}
 json.dump(j, open(tp, "w"), indent=1)
 print(json.dumps(out, indent=1)); print("trace hbm bytes/launch", hb)
+# the bench line was printed before this traffic figure existed: put the matching figure into the saved copy
+bp = os.path.join(R, "profiles/r01_front_bench.json")
+b = json.load(open(bp)); b["roofline"]["traffic"] = hb
+json.dump(b, open(bp, "w"))
