@@ -28,7 +28,7 @@ using namespace rtd;
 #define RTM_FRONT_OCC 4  // waves per SIMD the trace kernel's register allocation must leave room for
 #endif
 #ifndef RTM_SHADE_OCC
-#define RTM_SHADE_OCC 3  // waves per SIMD the shade kernel's register allocation must leave room for
+#define RTM_SHADE_OCC 4  // waves per SIMD the shade kernel's register allocation must leave room for (128 VGPRs: shade and trace waves of concurrent chunks share a SIMD)
 #endif
 #ifndef RTM_FWALK_UNROLL
 #define RTM_FWALK_UNROLL 2
@@ -558,7 +558,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     bool exhausted = sq >= A.nq;
     uint64_t dg_steps = 0, dg_step_lanes = 0, dg_walks = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_refills = 0, dg_refill_lanes = 0;  // STATS only, wave-uniform
 
+    uint32_t dg_ray_its = 0;  // STATS: loop iterations this lane's ray took part in
     auto finish_ray = [&]() __attribute__((always_inline)) {
+        if (STATS) { atomicMax(out_cnt + 26, (unsigned long long)(dg_ray_its & 0xFFFFu)); atomicMax(out_cnt + 27, (unsigned long long)(dg_ray_its >> 16)); }
         FrontResult r;
         r.t = bt; r.tri = btri; r.model = bm;
         A.res[at64(3, (int)(q & 3u), q >> 2)] = r;
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     sgn = mw;
                     fl = F_FRESH; arr = 6u;
                     bm = kNoId; btri = kNoId; bobj = kNoId; bt = 0.0;
+                    if (STATS) dg_ray_its = 0;
                     st = TS_TRAV;
                 }
                 const uint32_t want = (uint32_t)__popcll(idle);
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             if (nW + nT == 0u) break;
             if (nT == 0u || (nW != 0u && nT * 64u < A.t_test_frac * (nW + nT))) {
                 if (STATS) { dg_walks++; dg_walk_lanes += nW; dg_t0 = __builtin_amdgcn_s_memtime(); }
+                if (STATS && mine && !(fl & F_OPEN)) dg_ray_its++;
 #pragma unroll
                 for (int u = 0; u < RTM_FWALK_UNROLL; ++u) {
                     if (st == TS_TRAV && model_i == mm && !(fl & F_OPEN)) {
@@ -750,6 +754,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 if (STATS) dg_tw += __builtin_amdgcn_s_memtime() - dg_t0;
             } else {
                 if (STATS) { dg_steps++; dg_step_lanes += nT; dg_t0 = __builtin_amdgcn_s_memtime(); }
+                if (STATS && mine && (fl & F_OPEN)) dg_ray_its += 1u << 16;
                 if (mine && (fl & F_OPEN)) {
                     bool have = (fl & F_HAVE) != 0u;
                     // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
