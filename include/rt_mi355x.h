@@ -121,7 +121,7 @@ const char* rtm_version(void);
 /* Scheduling knobs of the device path (no effect on results; no counterpart in the reference).  Keys:
  *   "front_max_paths"  sample paths kept in flight per band of rows (workspace: ~700 B each; default 32 Mi),
  *   "front_cull"       1 (default): shadow rays whose light is behind the surface (main.rs:96 fails) are not traced,
- *   "front_refill"     idle lanes per wave at which the trace kernel fetches new rays (default 16),
+ *   "front_refill"     idle lanes per wave at which the trace kernel fetches new rays (default 24),
  *   "front_streams"    chunks of a frame in flight at once on internal streams (1..4, default 2),
  *   "front_claim"      ray items a trace wave claims from a sub-queue at a time (>= 16, default 128),
  *   "front_steal"      sub-queues of other waves a trace wave may try when its own are empty (default 8).

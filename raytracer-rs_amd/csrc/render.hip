@@ -43,7 +43,7 @@ static hipEvent_t g_front_stagger[kFrontStreamsMax] = {};  // chunk c + 1 starts
 static uint32_t g_front_stagger_on = 0, g_front_trace_wgs_per_cu = RTM_FRONT_OCC;
 static bool g_front_debug_rounds = false;
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
-static uint32_t g_front_refill = 16, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
+static uint32_t g_front_refill = 24, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
 struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
     char* base = nullptr;
     size_t bytes = 0;

@@ -122,7 +122,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
     finally:
         rtm_gpu.set_tuning("front_max_paths", 32 << 20)
         rtm_gpu.set_tuning("front_cull", 1)
-        rtm_gpu.set_tuning("front_refill", 16)
+        rtm_gpu.set_tuning("front_refill", 24)
         rtm_gpu.set_tuning("front_streams", 2)
         rtm_gpu.set_tuning("front_claim", 128)
         rtm_gpu.set_tuning("front_steal", 8)
