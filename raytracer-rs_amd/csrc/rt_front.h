@@ -31,7 +31,7 @@ using namespace rtd;
 #define RTM_SHADE_OCC 4  // waves per SIMD the shade kernel's register allocation must leave room for (128 VGPRs: shade and trace waves of concurrent chunks share a SIMD)
 #endif
 #ifndef RTM_FWALK_UNROLL
-#define RTM_FWALK_UNROLL 2
+#define RTM_FWALK_UNROLL 4
 #endif
 #ifndef RTM_FTRI_WIDE
 #define RTM_FTRI_WIDE 4
