@@ -173,6 +173,13 @@ int rtm_trace_rays(const rtm_scene_dev* scene, uint64_t n, const double* rays6, 
  * c>0 ? c^(1/2.2) : 0, then (c*255.0) saturating-truncating cast.  d_rgb, d_rgb8: device pointers. */
 int rtm_tonemap_device(const double* d_rgb, uint64_t n_pixels, int gamma, uint8_t* d_rgb8, void* stream);
 
+/* main.rs:153-185 in one call for callers that only want the 8-bit image: renders like
+ * rtm_render_device, converts on the device with rtm_tonemap_device's rule and copies local_rows*width*3 bytes to the
+ * HOST buffer out_rgb8 -- an eighth of the f64 framebuffer over PCIe.  out_seconds (may be NULL): wall time of
+ * render + conversion + copy, the bracket of main.rs:156-187.  Synchronous. */
+int rtm_render_rgb8(const rtm_scene_dev* scene, const rtm_params* params, int gamma, uint8_t* out_rgb8,
+                    double* out_seconds);
+
 /* De-interleave gathered per-rank row blocks into the row-major framebuffer (multi-GPU assemble):
  * d_blocks holds n_ranks blocks, block g = rows y = g + k*n_ranks packed densely; all device pointers. */
 int rtm_deinterleave_device(const double* d_blocks, uint32_t width, uint32_t height, uint32_t n_ranks,
@@ -200,6 +207,15 @@ int rtm_frontend_add_triangles(rtm_frontend* fe, uint64_t n_tris, const float* p
 const rtm_scene* rtm_frontend_scene(const rtm_frontend* fe);
 int rtm_frontend_size(const rtm_frontend* fe, uint32_t* width, uint32_t* height);
 int rtm_frontend_free(rtm_frontend* fe);
+
+/* ---- The reference's whole program, for machines without a Rust toolchain.
+ * rtm_write_bmp: what buffer.save(&args.output) writes for an ImageBuffer<Rgb<u8>> (main.rs:173,190; `image` crate
+ * 0.25.1 BMP encoder: 54-byte header, 24 bpp, bottom-up, BGR, rows padded to 4 bytes); rgb8 = height*width*3, row-major,
+ * top row first.  rtm_cli_main: main() (main.rs:134-192) with clap's arguments (main.rs:17-31): <scene> [-o output.bmp]
+ * [-s 20] [--gamma-correction]; prints "Rendered <output> in <time>" (main.rs:188); returns the process exit status
+ * (0 ok, 1 error, 2 usage).  The binary raytracer-rs_amd/lib/raytracer_mi355x only calls it. */
+int rtm_write_bmp(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
+int rtm_cli_main(int argc, const char* const* argv);
 
 #ifdef __cplusplus
 }

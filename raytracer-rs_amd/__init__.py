@@ -107,6 +107,9 @@ _lib.rtm_profile_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, _vp, 
 _lib.rtm_trace_rays.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
 _lib.rtm_tonemap_device.argtypes = [_vp, C.c_uint64, C.c_int, _vp, _vp]
 _lib.rtm_deinterleave_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]
+_lib.rtm_render_rgb8.argtypes = [_vp, C.POINTER(RtmParams), C.c_int, _vp, C.POINTER(C.c_double)]
+_lib.rtm_write_bmp.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _vp]
+_lib.rtm_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
 _lib.rtm_f64_ops_selftest.argtypes = [C.c_uint64, _vp, _vp, _vp]
 _lib.rtm_frontend_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(_vp)]
 _lib.rtm_frontend_add_triangles.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, _vp]
@@ -119,7 +122,7 @@ EXPORTED_SYMBOLS = (
     "rtm_local_rows", "rtm_init", "rtm_shutdown", "rtm_last_error", "rtm_version", "rtm_set_tuning", "rtm_render", "rtm_scene_upload",
     "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_profile_render_device", "rtm_trace_rays", "rtm_tonemap_device",
     "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
-    "rtm_frontend_size", "rtm_frontend_free")
+    "rtm_frontend_size", "rtm_frontend_free", "rtm_render_rgb8", "rtm_write_bmp", "rtm_cli_main")
 
 
 def raw_lib() -> C.CDLL:
@@ -293,6 +296,15 @@ class Scene:
         _check(_lib.rtm_profile_render_device(self.device_handle(), C.byref(params), d_rgb, stream or None, C.byref(pr)))
         return {k: getattr(pr, k) for k, _ in RtmProfile._fields_}
 
+    def render_rgb8(self, spp: int = 20, seed: int = 0, gamma: bool = False, width: int | None = None,
+                    height: int | None = None, **kw) -> tuple[np.ndarray, float]:
+        """rtm_render_rgb8 (main.rs:153-185): the frame as [rows, width, 3] u8 and the wall seconds it took."""
+        p = make_params(width or self.width, height or self.height, spp=spp, seed=seed, **kw)
+        out = np.zeros((local_rows(p), p.width, 3), dtype=np.uint8)
+        sec = C.c_double()
+        _check(_lib.rtm_render_rgb8(self.device_handle(), C.byref(p), int(gamma), _ptr(out), C.byref(sec)))
+        return out, sec.value
+
     def trace(self, rays6) -> dict:
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
         n = rays6.shape[0]
@@ -306,6 +318,19 @@ class Scene:
 
 def tonemap_device(d_rgb: int, n_pixels: int, gamma: bool, d_rgb8: int, stream: int = 0):
     _check(_lib.rtm_tonemap_device(d_rgb, n_pixels, int(gamma), d_rgb8, stream or None))
+
+
+def write_bmp(path: str, rgb8) -> None:
+    """rtm_write_bmp: rgb8 = [height, width, 3] u8, top row first (what main.rs:190 saves)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    _check(_lib.rtm_write_bmp(os.fsencode(path), rgb8.shape[1], rgb8.shape[0], _ptr(rgb8)))
+
+
+def cli_main(argv) -> int:
+    """rtm_cli_main: the reference's main() (main.rs:134-192); argv[0] is the program name.  Returns the exit status."""
+    args = [os.fsencode(a) for a in argv]
+    arr = (C.c_char_p * len(args))(*args)
+    return int(_lib.rtm_cli_main(len(args), arr))
 
 
 def deinterleave_device(d_blocks: int, width: int, height: int, n_ranks: int, d_rgb: int, stream: int = 0):

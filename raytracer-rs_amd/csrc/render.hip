@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -934,6 +935,36 @@ int rtm_tonemap_device(const double* d_rgb, uint64_t n_pixels, int gamma, uint8_
     if (n == 0) return RTM_OK;
     hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, n, gamma, d_rgb8);
     HIP_TRY(hipGetLastError());
+    return RTM_OK;
+}
+
+int rtm_render_rgb8(const rtm_scene_dev* sd, const rtm_params* p, int gamma, uint8_t* out_rgb8, double* out_seconds) {
+    if (int rc = need_init()) return rc;
+    if (!sd || !out_rgb8) return rtm_internal_fail(RTM_ERR_INVALID, "scene or output is null");
+    if (int rc = check_params(p)) return rc;
+    const size_t n_px = (size_t)rtm_local_rows(p) * p->width;
+    if (n_px == 0) {
+        if (out_seconds) *out_seconds = 0.0;
+        return RTM_OK;
+    }
+    double* d_rgb = nullptr;
+    uint8_t* d_rgb8 = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rgb, n_px * 3 * sizeof(double)));
+    if (hipMalloc((void**)&d_rgb8, n_px * 3) != hipSuccess) {
+        (void)hipFree(d_rgb);
+        return rtm_internal_fail(RTM_ERR_DEVICE, "rtm_render_rgb8: out of device memory");
+    }
+    // the bracket of main.rs:156-187: render, then the conversion to 8 bits (here on the device), image in host memory
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = rtm_render_device(sd, p, d_rgb, nullptr, nullptr, nullptr, nullptr);
+    if (rc == RTM_OK) rc = rtm_tonemap_device(d_rgb, n_px, gamma, d_rgb8, nullptr);
+    hipError_t e = hipSuccess;
+    if (rc == RTM_OK) e = hipMemcpy(out_rgb8, d_rgb8, n_px * 3, hipMemcpyDeviceToHost);
+    if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_rgb8);
+    if (rc != RTM_OK) return rc;
+    if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("rtm_render_rgb8: ") + hipGetErrorString(e));
     return RTM_OK;
 }
 
