@@ -40,8 +40,7 @@ constexpr int kFrontStreamsMax = 4;
 static uint32_t g_front_streams = 2;  // chunks of a frame in flight at once; env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
 static hipStream_t g_front_stream[kFrontStreamsMax] = {};
 static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
-static hipEvent_t g_front_stagger[kFrontStreamsMax] = {};  // chunk c + 1 starts when chunk c has finished its first shade launch
-static uint32_t g_front_stagger_on = 0, g_front_trace_wgs_per_cu = RTM_FRONT_OCC;
+static uint32_t g_front_trace_wgs_per_cu = RTM_FRONT_OCC;  // trace workgroups per CU (RTM_FRONT_TRACE_WGS)
 static bool g_front_debug_rounds = false;
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
 static uint32_t g_front_refill = 24, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
@@ -293,10 +292,8 @@ int rtm_init(int device) {
         for (int i = 0; i < kFrontStreamsMax; ++i) {
             HIP_TRY(hipStreamCreateWithFlags(&g_front_stream[i], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&g_front_join[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&g_front_stagger[i], hipEventDisableTiming));
         }
     }
-    if (const char* e = std::getenv("RTM_FRONT_STAGGER")) g_front_stagger_on = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_TRACE_WGS")) g_front_trace_wgs_per_cu = (uint32_t)std::max(1, std::min(RTM_FRONT_OCC, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_CULL")) g_front_cull = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(64ll, std::atoll(e));
@@ -327,7 +324,6 @@ int rtm_shutdown(void) {
         for (int i = 0; i < kFrontStreamsMax; ++i) {
             (void)hipStreamDestroy(g_front_stream[i]);
             (void)hipEventDestroy(g_front_join[i]);
-            (void)hipEventDestroy(g_front_stagger[i]);
         }
     }
     if (g_front_ws.base) (void)hipFree(g_front_ws.base);
@@ -607,7 +603,6 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.nq = nq; A.cap_l = ((((A.np + 63u) / 64u) + nq - 1) / nq) * 64u; A.cap_i = A.cap_l * 3u; A.cap_items = nq * A.cap_i;
         A.ctr = (uint32_t*)(B + o_ctr);
         const uint32_t shade_wgs0 = shade_wgs;
-        if (g_front_stagger_on && n_conc > 1 && chunk > 0) HIP_TRY(hipStreamWaitEvent(stream, g_front_stagger[(chunk - 1) % kFrontStreamsMax], 0));
         for (uint32_t r = 0; r < rounds; ++r) {
             mark(0, false, stream);
             if (r == 0) {
@@ -618,7 +613,6 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
             }
             mark(0, true, stream);
-            if (g_front_stagger_on && n_conc > 1 && r == g_front_stagger_on - 1u) HIP_TRY(hipEventRecord(g_front_stagger[chunk % kFrontStreamsMax], stream));
             if (prof && prof->d_items && !prof->keep_cull)
                 hipLaunchKernelGGL(front_sum_items_kernel, dim3(32), dim3(256), 0, stream, A.ctr, nq, prof->d_items);
             if (r + 1 < rounds) {  // the last round only finalises
