@@ -558,9 +558,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     bool exhausted = sq >= A.nq;
     uint64_t dg_steps = 0, dg_step_lanes = 0, dg_walks = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_refills = 0, dg_refill_lanes = 0;  // STATS only, wave-uniform
 
-    uint32_t dg_ray_its = 0;  // STATS: loop iterations this lane's ray took part in
+    uint32_t dg_ray_its = 0, dg_max_walks = 0, dg_max_tests = 0;  // STATS: walk iterations (low half) and test steps of this lane's ray; the lane's maxima
     auto finish_ray = [&]() __attribute__((always_inline)) {
-        if (STATS) { atomicMax(out_cnt + 26, (unsigned long long)(dg_ray_its & 0xFFFFu)); atomicMax(out_cnt + 27, (unsigned long long)(dg_ray_its >> 16)); }
+        if (STATS) { dg_max_walks = max(dg_max_walks, dg_ray_its & 0xFFFFu); dg_max_tests = max(dg_max_tests, dg_ray_its >> 16); }
         FrontResult r;
         r.t = bt; r.tri = btri; r.model = bm;
         A.res[at64(3, (int)(q & 3u), q >> 2)] = r;
@@ -841,6 +841,17 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         }
     }
 #undef RTF_DDA_ADVANCE
+    if (STATS) {  // longest ray of the wave (one atomic per wave, not per ray)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dg_max_walks = max(dg_max_walks, (uint32_t)__shfl_xor((int)dg_max_walks, off, 64));
+            dg_max_tests = max(dg_max_tests, (uint32_t)__shfl_xor((int)dg_max_tests, off, 64));
+        }
+        if (lane == 0) {
+            atomicMax(out_cnt + 26, (unsigned long long)dg_max_walks);
+            atomicMax(out_cnt + 27, (unsigned long long)dg_max_tests);
+        }
+    }
     if (STATS && lane == 0) {
         const unsigned long long el = (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_begin);
         atomicAdd(out_cnt + 20, el);
