@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override width=height (0 = scene file's size)")
     ap.add_argument("--soup-tris", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", choices=("f64", "u8"), default="f64",
+                    help="N > 1: what rank 0 collects -- the f64 framebuffer (default, the parity path) or the 8-bit image "
+                         "after the device tonemap (main.rs:173-185; an eighth of the bytes)")
     args = ap.parse_args()
 
     import torch
@@ -130,11 +133,17 @@ def main():
     from raytracer_rs_amd.distributed import gather_frame
     scratch = {}
 
+    local8 = torch.empty(rows, W, 3, dtype=torch.uint8, device="cuda") if args.gather == "u8" else None
+
     def step():
         scene.render_device(p_local, local.data_ptr(), stream=stream.cuda_stream)
         if world > 1:
             # one gather of the compact row blocks to rank 0 over xGMI (RCCL), then de-interleave
-            gather_frame(local, H, W, rank, world, deinterleave_device=rtm.deinterleave_device, scratch=scratch)
+            if local8 is not None:
+                rtm.tonemap_device(local.data_ptr(), rows * W, False, local8.data_ptr(), stream=stream.cuda_stream)
+                gather_frame(local8, H, W, rank, world, scratch=scratch)
+            else:
+                gather_frame(local, H, W, rank, world, deinterleave_device=rtm.deinterleave_device, scratch=scratch)
 
     def barrier():
         if world > 1:
@@ -195,7 +204,7 @@ def main():
                        "rays_note": "rays the reference casts for this frame (exact counters, pinned to the oracle's). The device path "
                                     "answers shadow rays whose light is behind the surface (main.rs:96 fails) without tracing them, and "
                                     f"only rays that enter a model's box reach the trace kernel ({prof['traced_rays']} on this rank)",
-                       "parallelism": f"row-interleave x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
+                       "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>" if single else "rtf::front_trace_kernel<false, true>",
                          "kernel_ms": kern_ms, "launches_per_frame": n_launch, "algorithmic_bytes_per_launch": abytes,

@@ -17,8 +17,10 @@ def rows_of_rank(height: int, rank: int, world: int) -> int:
 
 def gather_frame(local_rows: torch.Tensor, height: int, width: int, rank: int, world: int, deinterleave_device=None,
                  scratch: dict | None = None):
-    """local_rows: [rows_of_rank, width, 3] f64 on this rank's device.  Returns the [height, width, 3] frame on
-    rank 0 and None elsewhere.  `scratch` (optional dict) keeps the gather/frame buffers between frames."""
+    """local_rows: [rows_of_rank, width, 3] on this rank's device -- f64 (the parity path) or u8 after
+    rtm_tonemap_device (an eighth of the bytes when only the bitmap is wanted, main.rs:173-185).
+    Returns the [height, width, 3] frame on rank 0 and None elsewhere.  `scratch` (optional dict) keeps the
+    gather/frame buffers between frames."""
     if world == 1:
         return local_rows
     max_rows = rows_of_rank(height, 0, world)
@@ -28,14 +30,14 @@ def gather_frame(local_rows: torch.Tensor, height: int, width: int, rank: int, w
         pad[: local_rows.shape[0]] = local_rows
     scratch = scratch if scratch is not None else {}
     if rank == 0:
-        key = (max_rows, width, world, str(local_rows.device))
+        key = (max_rows, width, world, str(local_rows.device), local_rows.dtype)
         if scratch.get("key") != key:
             scratch["key"] = key
             scratch["gathered"] = local_rows.new_empty((world, max_rows, width, 3))
             scratch["frame"] = local_rows.new_empty((height, width, 3))
         gathered, frame = scratch["gathered"], scratch["frame"]
         dist.gather(pad, list(gathered.unbind(0)), dst=0)
-        if deinterleave_device is not None and height % world == 0 and gathered.is_cuda:
+        if deinterleave_device is not None and height % world == 0 and gathered.is_cuda and gathered.dtype == torch.float64:
             deinterleave_device(gathered.data_ptr(), width, height, world, frame.data_ptr())
         else:
             for g in range(world):

@@ -29,11 +29,14 @@ def _worker(rank, world, port, height, width, out_path):
     scratch = {}
     for _ in range(2):  # second call reuses the buffers
         frame = gather_frame(torch.from_numpy(blk), height, width, rank, world, scratch=scratch)
+    # the 8-bit variant: every rank converts its rows (main.rs:33-37), one gather of an eighth of the bytes
+    frame8 = gather_frame(torch.from_numpy(oracle.to_rgb8(blk)), height, width, rank, world, scratch=scratch)
     if rank == 0:
         full = sc.render(spp=2, seed=3, width=width, height=height, n_threads=2)["rgb"]
-        np.save(out_path, np.array([np.array_equal(frame.numpy(), full)]))
+        ok8 = frame8.dtype == torch.uint8 and np.array_equal(frame8.numpy(), oracle.to_rgb8(full))
+        np.save(out_path, np.array([np.array_equal(frame.numpy(), full) and ok8]))
     else:
-        assert frame is None
+        assert frame is None and frame8 is None
     dist.barrier()
     dist.destroy_process_group()
 
