@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 mat = ldU(PU_MAT);
                 FrontResult r0 = A.res[at64(3, 0, p)];
                 const FrontResult l_r1 = A.res[at64(3, 1, p)], l_r2 = A.res[at64(3, 2, p)];
-                held_t = ldD(PF_HELD); held_tri = ldU(PU_HTRI); held_m = ldU(PU_HM);
+                if (nL > 2u) { held_t = ldD(PF_HELD); held_tri = ldU(PU_HTRI); held_m = ldU(PU_HM); }  // (only then can a result be held)
                 sba0 = ldD(PF_SBA); sba1 = ldD(PF_SBA + 1);
                 nn = ldD3(PF_NRM);
                 dir0 = ldD3(PF_D0);
@@ -480,12 +480,13 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         if (valid && cont) {  // the state moves on
             stD3(PF_COL, col); stD(PF_ATT, att);
             stD3(PF_O, o); stD3(PF_D0, dir0); stD3(PF_NRM, nn);
-            stD(PF_BA0, ba0); stD(PF_SBA, sba0); stD(PF_SBA + 1, sba1); stD(PF_HELD, held_t);
+            stD(PF_BA0, ba0); stD(PF_SBA, sba0); stD(PF_SBA + 1, sba1);
+            if (nL > 2u) { stD(PF_HELD, held_t); stU(PU_HTRI, held_tri); stU(PU_HM, held_m); }
             if (nL > 2u) stD3(PF_DIFF, diff);
             stU(PU_FL, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT));
             stU(PU_CTR, bounce | (li << 16));
             stU(PU_HOBJ, h_obj); stU(PU_HMAT, h_mat); stU(PU_HKP, h_kp); stU(PU_MAT, mat);
-            stU(PU_HOME, home); stU(PU_HTRI, held_tri); stU(PU_HM, held_m);
+            stU(PU_HOME, home);
         }
     }
     if (lane == 0) {
