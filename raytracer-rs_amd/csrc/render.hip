@@ -42,6 +42,7 @@ static hipStream_t g_front_stream[kFrontStreamsMax] = {};
 static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
 static uint32_t g_front_trace_wgs_per_cu = RTM_FRONT_OCC;  // trace workgroups per CU (RTM_FRONT_TRACE_WGS)
 static bool g_front_debug_rounds = false;
+static uint32_t g_front_coop = 1;  // trace kernel: idle lanes test the entries of the last one or two testing rays of a wave
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
 static uint32_t g_front_refill = 24, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
 struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
@@ -283,6 +284,7 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_KERNEL")) g_kernel = std::string(e) == "wave" ? 0 : 2;
     if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_CLAIM")) g_front_claim = (uint32_t)std::max(16, std::atoi(e));
+    if (const char* e = std::getenv("RTM_FRONT_COOP")) g_front_coop = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_STEAL")) g_front_steal = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
     g_front_debug_rounds = std::getenv("RTM_FRONT_DEBUG_ROUNDS") != nullptr;
@@ -310,6 +312,7 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_cull" && (value == 0 || value == 1)) { g_front_cull = (uint32_t)value; return RTM_OK; }
     if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
     if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
+    if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
     if (k == "front_steal" && value >= 0 && value <= 4096) { g_front_steal = (uint32_t)value; return RTM_OK; }
     if (k == "front_streams" && value >= 1 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
     return rtm_internal_fail(RTM_ERR_INVALID, "unknown tuning key or value out of range: " + k);
@@ -595,7 +598,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
         A.cull = (stats && !(prof && prof->keep_cull) && !std::getenv("RTM_DIAG_KEEP_CULL")) ? 0u : g_front_cull;
         A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
-        A.claim = g_front_claim; A.steal = g_front_steal;
+        A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
         A.occ_words = occ_words;
         A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
         A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);

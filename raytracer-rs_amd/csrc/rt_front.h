@@ -90,6 +90,7 @@ struct FrontArgs {
     uint32_t cull;              // 1: shadow queries that cannot contribute (eff <= 0.001) are not traced
     uint32_t refill;            // trace kernel: fetch new items when at least this many lanes of a wave are idle
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
+    uint32_t coop;              // trace kernel: 1 = when at most two rays of a wave are testing, the other lanes test their entries
     uint32_t t_test_frac, t_min_lanes;
     uint32_t occ_words;
     double* D[2];               // path state, streamed from one buffer to the other every round
@@ -755,23 +756,76 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 if (STATS) dg_tw += __builtin_amdgcn_s_memtime() - dg_t0;
             } else {
                 if (STATS) { dg_steps++; dg_step_lanes += nT; dg_t0 = __builtin_amdgcn_s_memtime(); }
-                if (STATS && mine && (fl & F_OPEN)) dg_ray_its += 1u << 16;
-                if (mine && (fl & F_OPEN)) {
+                const bool testing = mine && (fl & F_OPEN);
+                if (STATS && testing) dg_ray_its += 1u << 16;
+                if (testing && (fl & F_WINIT)) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
+                    // list range [k, k_end), k < k_end, and the arrival mask: one 32-byte record
+                    const gptr<uint32_t> ci = cell_info + (size_t)k * 8;
+                    const uint32_t mw = ci[2 + (arr < 6u ? arr : 0u)];
+                    k_end = ci[1];
+                    k = ci[0];
+                    const uint32_t len = k_end - k;
+                    const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                    wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
+                    fl &= ~F_WINIT;
+                }
+                if (nT <= 2u && A.coop) {
+                    // One or two rays are testing (the end of a launch: a few long rays are left).  The other lanes test
+                    // the window's entries for them, one entry per lane (lanes 0-31 for the first ray, 32-63 for the
+                    // second), so a cell costs one step whatever its length; the accepted entries are then applied to
+                    // the ray in list order, exactly as the sequential loop does (core.rs:140-142).
+                    const unsigned long long tm = __ballot(testing);
+                    const int la = __ffsll((long long)tm) - 1, lb = 63 - __clzll((long long)tm);  // (lb == la with one ray)
+                    const bool upper = lane >= 32u;
+                    const int src = upper ? lb : la;
+                    const V3 so = mk(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+                    const V3 sd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+                    const uint32_t sk = (uint32_t)__shfl((int)k, src, 64), swm = (uint32_t)__shfl((int)wmask, src, 64);
+                    const uint32_t e = lane & 31u;
+                    const bool act = (!upper || nT == 2u) && ((swm >> e) & 1u);
+                    bool okc = false;
+                    double ttc = 0.0;
+                    uint32_t tic = 0;
+                    if (act) {
+                        const gptr<double> tp = cell_rec + (uint32_t)((sk + e) * 10u);
+                        const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
+                        tic = (uint32_t)__double_as_longlong(tp[9]);
+                        const V3 pv = cross(sd, e2);
+                        const double det = dot(e1, pv);
+                        const double inv = 1.0 / det;
+                        const V3 tv = so - v0;
+                        const double u = dot(tv, pv) * inv;
+                        const V3 qv = cross(tv, e1);
+                        const double v = dot(sd, qv) * inv;
+                        ttc = dot(e2, qv) * inv;
+                        okc = !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(ttc < 0.0);
+                    }
+                    const unsigned long long okm = __ballot(okc);
+                    for (uint32_t h = 0; h < nT; ++h) {  // (wave-uniform)
+                        const uint32_t owner = h ? (uint32_t)lb : (uint32_t)la;
+                        unsigned long long om = okm & (h ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
+                        while (om) {  // ascending entry index = list order
+                            const int c = __ffsll((long long)om) - 1;
+                            om &= om - 1ull;
+                            const double tc = __shfl(ttc, c, 64);
+                            const uint32_t trc = (uint32_t)__shfl((int)tic, c, 64);
+                            if (lane == owner) {
+                                const bool take = !(fl & F_HAVE) || tc < m_t;
+                                m_t = take ? tc : m_t;
+                                m_tri = take ? trc : m_tri;
+                                fl |= F_HAVE;
+                            }
+                        }
+                    }
+                    if (testing) {
+                        if (STATS) cnt.v[C_TRI] += (uint32_t)__popc(wmask);
+                        wmask = 0u;
+                    }
+                } else if (testing) {
                     bool have = (fl & F_HAVE) != 0u;
                     // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
                     // the same side).  Entries are applied in list order (core.rs:140-142).
-                    if (fl & F_WINIT) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
-                        // list range [k, k_end), k < k_end, and the arrival mask: one 32-byte record
-                        const gptr<uint32_t> ci = cell_info + (size_t)k * 8;
-                        const uint32_t mw = ci[2 + (arr < 6u ? arr : 0u)];
-                        k_end = ci[1];
-                        k = ci[0];
-                        const uint32_t len = k_end - k;
-                        const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
-                        wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
-                        fl &= ~F_WINIT;
-                    }
                     uint32_t ti[RTM_FTRI_WIDE];
                     double tt[RTM_FTRI_WIDE];
                     bool ok[RTM_FTRI_WIDE];
@@ -816,14 +870,14 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     }
                     fl = (fl & ~F_HAVE) | (have ? F_HAVE : 0u);
                     if (STATS) cnt.v[C_TRI] += cntw;
-                    if (wmask == 0u) {  // window done: the next 32 entries of a long list, or the cell is finished
-                        if (k_end - k > 32u) {
-                            k += 32u;
-                            const uint32_t len = k_end - k;
-                            wmask = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
-                        } else {
-                            fl &= ~F_OPEN;
-                        }
+                }
+                if (testing && wmask == 0u) {  // window done: the next 32 entries of a long list, or the cell is finished
+                    if (k_end - k > 32u) {
+                        k += 32u;
+                        const uint32_t len = k_end - k;
+                        wmask = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                    } else {
+                        fl &= ~F_OPEN;
                     }
                 }
                 if (STATS) dg_tt += __builtin_amdgcn_s_memtime() - dg_t0;
