@@ -125,7 +125,7 @@ const char* rtm_version(void);
  *   "front_streams"    chunks of a frame in flight at once on internal streams (1..4, default 2),
  *   "front_claim"      ray items a trace wave claims from a sub-queue at a time (>= 16, default 128),
  *   "front_steal"      sub-queues of other waves a trace wave may try when its own are empty (default 8),
- *   "front_coop"       1 (default): when only one or two rays of a wave are testing triangles, its other lanes test
+ *   "front_coop"       1 (default): when at most four rays of a wave are testing triangles, its other lanes test
  *                      their cells' entries for them.
  * Returns RTM_ERR_INVALID for an unknown key or a value out of range.  The same knobs are read from the
  * environment (RTM_FRONT_MAX_PATHS, ...) by rtm_init. */

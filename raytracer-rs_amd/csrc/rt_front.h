@@ -90,7 +90,7 @@ struct FrontArgs {
     uint32_t cull;              // 1: shadow queries that cannot contribute (eff <= 0.001) are not traced
     uint32_t refill;            // trace kernel: fetch new items when at least this many lanes of a wave are idle
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
-    uint32_t coop;              // trace kernel: 1 = when at most two rays of a wave are testing, the other lanes test their entries
+    uint32_t coop;              // trace kernel: 1 = when at most four rays of a wave are testing, the other lanes test their entries
     uint32_t t_test_frac, t_min_lanes;
     uint32_t occ_words;
     double* D[2];               // path state, streamed from one buffer to the other every round
@@ -769,51 +769,66 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
                     fl &= ~F_WINIT;
                 }
-                if (nT <= 2u && A.coop) {
-                    // One or two rays are testing (the end of a launch: a few long rays are left).  The other lanes test
-                    // the window's entries for them, one entry per lane (lanes 0-31 for the first ray, 32-63 for the
-                    // second), so a cell costs one step whatever its length; the accepted entries are then applied to
-                    // the ray in list order, exactly as the sequential loop does (core.rs:140-142).
-                    const unsigned long long tm = __ballot(testing);
-                    const int la = __ffsll((long long)tm) - 1, lb = 63 - __clzll((long long)tm);  // (lb == la with one ray)
-                    const bool upper = lane >= 32u;
-                    const int src = upper ? lb : la;
+                if (nT <= 4u && A.coop) {
+                    // A few rays are testing (the end of a launch: some long rays are left).  The other lanes test the
+                    // window's entries for them -- 32 lanes per ray and one entry per lane with one or two rays, 16 lanes
+                    // and two entries with three or four -- so a cell costs one step whatever its length; the accepted
+                    // entries are then applied to the ray in list order, exactly as the sequential loop does
+                    // (core.rs:140-142).  (Eight rays with four entries per lane spill registers: measured slower.)
+                    unsigned long long tm = __ballot(testing);
+                    const uint32_t gsh = nT <= 2u ? 5u : 4u;            // log2 of the lanes per ray
+                    const uint32_t grp = lane >> gsh;                   // the ray this lane helps
+                    int owner[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        owner[h] = tm ? __ffsll((long long)tm) - 1 : 0;
+                        tm &= tm - 1ull;
+                    }
+                    const int src = grp == 0u ? owner[0] : grp == 1u ? owner[1] : grp == 2u ? owner[2] : owner[3];
                     const V3 so = mk(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
                     const V3 sd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
                     const uint32_t sk = (uint32_t)__shfl((int)k, src, 64), swm = (uint32_t)__shfl((int)wmask, src, 64);
-                    const uint32_t e = lane & 31u;
-                    const bool act = (!upper || nT == 2u) && ((swm >> e) & 1u);
-                    bool okc = false;
-                    double ttc = 0.0;
-                    uint32_t tic = 0;
-                    if (act) {
-                        const gptr<double> tp = cell_rec + (uint32_t)((sk + e) * 10u);
-                        const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
-                        tic = (uint32_t)__double_as_longlong(tp[9]);
-                        const V3 pv = cross(sd, e2);
-                        const double det = dot(e1, pv);
-                        const double inv = 1.0 / det;
-                        const V3 tv = so - v0;
-                        const double u = dot(tv, pv) * inv;
-                        const V3 qv = cross(tv, e1);
-                        const double v = dot(sd, qv) * inv;
-                        ttc = dot(e2, qv) * inv;
-                        okc = !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(ttc < 0.0);
+                    const uint32_t passes = 32u >> gsh;                 // entries per lane
+                    bool okc[2] = {false, false};
+                    double ttc[2] = {0.0, 0.0};
+                    uint32_t tic[2] = {0u, 0u};
+#pragma unroll
+                    for (uint32_t ps = 0; ps < 2u; ++ps) {
+                        if (ps >= passes) break;
+                        const uint32_t e = (lane & ((1u << gsh) - 1u)) + (ps << gsh);
+                        if (grp < nT && ((swm >> e) & 1u)) {
+                            const gptr<double> tp = cell_rec + (uint32_t)((sk + e) * 10u);
+                            const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
+                            tic[ps] = (uint32_t)__double_as_longlong(tp[9]);
+                            const V3 pv = cross(sd, e2);
+                            const double det = dot(e1, pv);
+                            const double inv = 1.0 / det;
+                            const V3 tv = so - v0;
+                            const double u = dot(tv, pv) * inv;
+                            const V3 qv = cross(tv, e1);
+                            const double v = dot(sd, qv) * inv;
+                            ttc[ps] = dot(e2, qv) * inv;
+                            okc[ps] = !(fabs(det) < kF64Eps) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(ttc[ps] < 0.0);
+                        }
                     }
-                    const unsigned long long okm = __ballot(okc);
+                    const unsigned long long okm[2] = {__ballot(okc[0]), __ballot(okc[1])};
+                    const unsigned long long gmask = gsh == 5u ? 0xFFFFFFFFull : 0xFFFFull;
                     for (uint32_t h = 0; h < nT; ++h) {  // (wave-uniform)
-                        const uint32_t owner = h ? (uint32_t)lb : (uint32_t)la;
-                        unsigned long long om = okm & (h ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
-                        while (om) {  // ascending entry index = list order
-                            const int c = __ffsll((long long)om) - 1;
-                            om &= om - 1ull;
-                            const double tc = __shfl(ttc, c, 64);
-                            const uint32_t trc = (uint32_t)__shfl((int)tic, c, 64);
-                            if (lane == owner) {
-                                const bool take = !(fl & F_HAVE) || tc < m_t;
-                                m_t = take ? tc : m_t;
-                                m_tri = take ? trc : m_tri;
-                                fl |= F_HAVE;
+                        const uint32_t own = (uint32_t)(h == 0u ? owner[0] : h == 1u ? owner[1] : h == 2u ? owner[2] : owner[3]);
+#pragma unroll
+                        for (uint32_t ps = 0; ps < 2u; ++ps) {  // pass 0 holds the lower entries: ascending = list order
+                            unsigned long long om = okm[ps] & (gmask << (h << gsh));
+                            while (om) {
+                                const int c = __ffsll((long long)om) - 1;
+                                om &= om - 1ull;
+                                const double tc = __shfl(ttc[ps], c, 64);
+                                const uint32_t trc = (uint32_t)__shfl((int)tic[ps], c, 64);
+                                if (lane == own) {
+                                    const bool take = !(fl & F_HAVE) || tc < m_t;
+                                    m_t = take ? tc : m_t;
+                                    m_tri = take ? trc : m_tri;
+                                    fl |= F_HAVE;
+                                }
                             }
                         }
                     }
