@@ -40,11 +40,12 @@ constexpr int kFrontStreamsMax = 4;
 static uint32_t g_front_streams = 2;  // chunks of a frame in flight at once; env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
 static hipStream_t g_front_stream[kFrontStreamsMax] = {};
 static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
+static bool g_front_trace_wgs_env = false;
 static uint32_t g_front_trace_wgs_per_cu = RTM_FRONT_OCC;  // trace workgroups per CU (RTM_FRONT_TRACE_WGS)
 static bool g_front_debug_rounds = false;
 static uint32_t g_front_coop = 1;  // trace kernel: idle lanes test the entries of the last one or two testing rays of a wave
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
-static uint32_t g_front_refill = 24, g_front_cull = 1, g_front_shade_waves_per_cu = 32;  // shade waves per CU: a multiple of 4
+static uint32_t g_front_refill = 24, g_front_cull = 1, g_front_shade_waves_per_cu = 24;  // shade waves per CU: a multiple of 4
 struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per process (the library renders on one device, rtm_init)
     char* base = nullptr;
     size_t bytes = 0;
@@ -296,6 +297,7 @@ int rtm_init(int device) {
             HIP_TRY(hipEventCreateWithFlags(&g_front_join[i], hipEventDisableTiming));
         }
     }
+    g_front_trace_wgs_env = std::getenv("RTM_FRONT_TRACE_WGS") != nullptr;
     if (const char* e = std::getenv("RTM_FRONT_TRACE_WGS")) g_front_trace_wgs_per_cu = (uint32_t)std::max(1, std::min(RTM_FRONT_OCC, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_CULL")) g_front_cull = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(64ll, std::atoll(e));
@@ -582,7 +584,8 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t rounds = 2 + std::max<uint32_t>(p->max_bounces, 1) * B_rounds;
     const dim3 block(256);
     const uint32_t shade_wgs = nq / 4u;
-    const uint32_t trace_wgs = (uint32_t)g_num_cus * g_front_trace_wgs_per_cu;
+    // (a small chunk's launches are latency-bound: three workgroups per CU leave room for the other chunk's waves; measured)
+    const uint32_t trace_wgs = (uint32_t)g_num_cus * (g_front_trace_wgs_env ? g_front_trace_wgs_per_cu : (np_max >= ((size_t)8 << 20) ? (uint32_t)RTM_FRONT_OCC : 3u));
     uint32_t occ_total = 0;
     for (uint32_t w : sd->occ_words) occ_total += w;
     const bool all_lds = occ_total * 7u == occ_words;  // every bitmap is staged in LDS
