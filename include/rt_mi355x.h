@@ -125,6 +125,7 @@ const char* rtm_version(void);
  *   "front_streams"    chunks of a frame in flight at once on internal streams (1..4, default 2),
  *   "front_claim"      ray items a trace wave claims from a sub-queue at a time (>= 16, default 128),
  *   "front_steal"      sub-queues of other waves a trace wave may try when its own are empty (default 8),
+ *   "front_timed_events"  1: event pairs around the trace launches of ordinary frames (rtm_timed_events_collect),
  *   "front_coop"       1 (default): when at most four rays of a wave are testing triangles, its other lanes test
  *                      their cells' entries for them.
  * Returns RTM_ERR_INVALID for an unknown key or a value out of range.  The same knobs are read from the
@@ -165,6 +166,12 @@ typedef struct rtm_profile {
 } rtm_profile;
 int rtm_profile_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, void* stream,
                               rtm_profile* out);
+
+/* The dominant kernel timed in the regime of ordinary frames (no counterpart in the reference): after
+ * rtm_set_tuning("front_timed_events", 1) every rtm_render_device call records a HIP event pair around each trace-kernel
+ * launch, on the stream the kernel is launched on; this call waits for the device, returns the summed duration and the
+ * number of launches since the last call, and forgets them. */
+int rtm_timed_events_collect(double* out_trace_ms, uint32_t* out_trace_launches);
 
 /* Closest-hit of caller-supplied rays (hit, core.rs:68-92), for differential tests: rays6 = origin xyz,
  * direction xyz (host, n*6); outputs host arrays (obj n, tri n, t n, normal n*3). */

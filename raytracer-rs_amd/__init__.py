@@ -107,6 +107,7 @@ _lib.rtm_profile_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, _vp, 
 _lib.rtm_trace_rays.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
 _lib.rtm_tonemap_device.argtypes = [_vp, C.c_uint64, C.c_int, _vp, _vp]
 _lib.rtm_deinterleave_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]
+_lib.rtm_timed_events_collect.argtypes = [C.POINTER(C.c_double), _PU]
 _lib.rtm_render_rgb8.argtypes = [_vp, C.POINTER(RtmParams), C.c_int, _vp, C.POINTER(C.c_double)]
 _lib.rtm_write_bmp.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _vp]
 _lib.rtm_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = (
     "rtm_local_rows", "rtm_init", "rtm_shutdown", "rtm_last_error", "rtm_version", "rtm_set_tuning", "rtm_render", "rtm_scene_upload",
     "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_profile_render_device", "rtm_trace_rays", "rtm_tonemap_device",
     "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
-    "rtm_frontend_size", "rtm_frontend_free", "rtm_render_rgb8", "rtm_write_bmp", "rtm_cli_main")
+    "rtm_frontend_size", "rtm_frontend_free", "rtm_render_rgb8", "rtm_write_bmp", "rtm_cli_main", "rtm_timed_events_collect")
 
 
 def raw_lib() -> C.CDLL:
@@ -318,6 +319,14 @@ class Scene:
 
 def tonemap_device(d_rgb: int, n_pixels: int, gamma: bool, d_rgb8: int, stream: int = 0):
     _check(_lib.rtm_tonemap_device(d_rgb, n_pixels, int(gamma), d_rgb8, stream or None))
+
+
+def timed_events_collect() -> tuple[float, int]:
+    """rtm_timed_events_collect: (summed trace-kernel ms, launches) since set_tuning("front_timed_events", 1)."""
+    ms = C.c_double()
+    n = C.c_uint32()
+    _check(_lib.rtm_timed_events_collect(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
 
 
 def write_bmp(path: str, rgb8) -> None:

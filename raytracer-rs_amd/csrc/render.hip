@@ -43,6 +43,12 @@ static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
 static bool g_front_trace_wgs_env = false;
 static uint32_t g_front_trace_wgs_per_cu = RTM_FRONT_OCC;  // trace workgroups per CU (RTM_FRONT_TRACE_WGS)
 static bool g_front_debug_rounds = false;
+// rtm_set_tuning("front_timed_events", 1): ordinary frames carry a HIP event pair around every trace launch (on the
+// stream it is launched on) until rtm_timed_events_collect() reads them: bench.py's roofline line times the dominant
+// kernel in the same regime as the frames it reports.
+static bool g_front_timed_events = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_front_ev_pool;
+static size_t g_front_ev_used = 0;
 static uint32_t g_front_coop = 1;  // trace kernel: idle lanes test the entries of the last one or two testing rays of a wave
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
 static uint32_t g_front_refill = 24, g_front_cull = 1, g_front_shade_waves_per_cu = 24;  // shade waves per CU: a multiple of 4
@@ -315,6 +321,7 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
     if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
     if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
+    if (k == "front_timed_events" && (value == 0 || value == 1)) { g_front_timed_events = value != 0; return RTM_OK; }
     if (k == "front_steal" && value >= 0 && value <= 4096) { g_front_steal = (uint32_t)value; return RTM_OK; }
     if (k == "front_streams" && value >= 1 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
     return rtm_internal_fail(RTM_ERR_INVALID, "unknown tuning key or value out of range: " + k);
@@ -331,6 +338,12 @@ int rtm_shutdown(void) {
             (void)hipEventDestroy(g_front_join[i]);
         }
     }
+    for (auto& pr : g_front_ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    g_front_ev_pool.clear();
+    g_front_ev_used = 0;
     if (g_front_ws.base) (void)hipFree(g_front_ws.base);
     g_front_ws.base = nullptr;
     g_front_ws.bytes = 0;
@@ -529,6 +542,19 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                  uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof = nullptr) {
     const bool stats = d_cnt != nullptr;
     auto mark = [&](int kind, bool end, hipStream_t on) {  // event before / after a launch (profile runs only)
+        if (!prof && g_front_timed_events && kind == 1) {
+            if (!end) {
+                if (g_front_ev_used == g_front_ev_pool.size()) {
+                    hipEvent_t a = nullptr, b = nullptr;
+                    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+                    g_front_ev_pool.push_back({a, b});
+                }
+                (void)hipEventRecord(g_front_ev_pool[g_front_ev_used].first, on);
+            } else if (g_front_ev_used < g_front_ev_pool.size()) {
+                (void)hipEventRecord(g_front_ev_pool[g_front_ev_used++].second, on);
+            }
+            return;
+        }
         if (!prof || prof->keep_cull) return;
         if (!end) {
             hipEvent_t a, b;
@@ -840,6 +866,25 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
     (void)hipFree(d_buf);
     if (rc != RTM_OK) return rc;
     if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("profile: ") + hipGetErrorString(e));
+    return RTM_OK;
+}
+
+int rtm_timed_events_collect(double* out_trace_ms, uint32_t* out_trace_launches) {
+    if (int rc = need_init()) return rc;
+    if (!out_trace_ms || !out_trace_launches) return rtm_internal_fail(RTM_ERR_INVALID, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    double total = 0.0;
+    uint32_t n = 0;
+    for (size_t i = 0; i < g_front_ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_front_ev_pool[i].first, g_front_ev_pool[i].second) == hipSuccess) {
+            total += (double)ms;
+            ++n;
+        }
+    }
+    g_front_ev_used = 0;
+    *out_trace_ms = total;
+    *out_trace_launches = n;
     return RTM_OK;
 }
 

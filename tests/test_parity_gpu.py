@@ -131,6 +131,22 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("no_such_knob", 1)
 
 
+def test_timed_events(rtm_gpu, rtm_scene):
+    """rtm_timed_events_collect: one event pair per trace launch of ordinary frames, and none when switched off."""
+    s = rtm_scene("suzanne")
+    ref = s.render(spp=2, seed=1, width=96, height=64)
+    rtm_gpu.set_tuning("front_timed_events", 1)
+    try:
+        g = s.render(spp=2, seed=1, width=96, height=64)
+    finally:
+        rtm_gpu.set_tuning("front_timed_events", 0)
+    ms, n = rtm_gpu.timed_events_collect()
+    assert np.array_equal(g["rgb"], ref["rgb"])
+    assert n == 22 and ms > 0.0  # two chunks in flight, 11 trace launches each (10 bounces, one batch of two lights per vertex)
+    s.render(spp=2, seed=1, width=96, height=64)
+    assert rtm_gpu.timed_events_collect() == (0.0, 0)
+
+
 def test_profile_entry_point(rtm_gpu, rtm_scene):
     """rtm_profile_render_device (bench.py's roofline source): kernel times add up, and the work it reports is the
     reference's work minus what the product path provably skips (culled shadow rays, entries already tested)."""
