@@ -32,10 +32,17 @@ template <typename T>
 using gptr = const T __attribute__((address_space(1)))*;
 template <typename T>
 RTM_DEV gptr<T> as_global(const T* p) { return (gptr<T>)p; }
+// Scene data that nothing writes during a frame, read at wave-uniform addresses: through the constant address space the
+// compiler issues scalar loads (s_load into scalar registers, scalar data cache) instead of one vector load per lane.
+template <typename T>
+using cptr = const T __attribute__((address_space(4)))*;
+template <typename T>
+RTM_DEV cptr<T> as_const(const T* p) { return (cptr<T>)p; }
 
 RTM_DEV V3 mk(double x, double y, double z) { return V3{x, y, z}; }
 RTM_DEV V3 ld3(const double* p) { return V3{p[0], p[1], p[2]}; }
 RTM_DEV V3 ld3(gptr<double> p) { return V3{p[0], p[1], p[2]}; }
+RTM_DEV V3 ld3(cptr<double> p) { return V3{p[0], p[1], p[2]}; }
 RTM_DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 RTM_DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 RTM_DEV V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }

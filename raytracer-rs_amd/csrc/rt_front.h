@@ -132,6 +132,12 @@ template <bool STATS, bool ROUND0>
 __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
                                                               uint32_t* __restrict__ out_tri, unsigned long long* __restrict__ out_cnt) {
     const uint32_t lane = threadIdx.x & 63u;
+    // The analytic primitives and the model headers are read by every query of every path, at wave-uniform addresses,
+    // and nothing writes them during a frame: through the constant address space they come as scalar loads (one
+    // s_load_dwordx8 per sphere) instead of one vector load per lane with its latency in every loop iteration.
+    const cptr<double> sph_c = as_const(S.spheres), pl_c = as_const(S.planes);
+    const cptr<uint32_t> sph_ids_c = as_const(S.sph_ids), pl_ids_c = as_const(S.pl_ids);
+    const cptr<RtmDevModel> models_c = as_const(S.models);
     // One sub-list per wave (the grid has exactly nq waves): nothing is appended with atomics.  (Device-scope atomics
     // resolve outside the per-XCD L2 on this part; ~10 ns each when they share an address, which made a single queue
     // counter the bottleneck of both kernels.)
@@ -378,27 +384,41 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     }
                 };
                 const double a = dot(dir, dir);
-                for (uint32_t i = 0; i < S.n_spheres; ++i) {
-                    if (STATS) cnt.v[C_SPHERE]++;
-                    const double* sp = S.spheres + (size_t)i * 4;
-                    const V3 oc = o - ld3(sp);
-                    const double b = 2.0 * dot(dir, oc);
-                    const double c = dot(oc, oc) - sp[3] * sp[3];
-                    const double disc = b * b - 4.0 * a * c;
-                    if (disc < 0.0) continue;
-                    const double t = (-b - __builtin_sqrt(disc)) / (2.0 * a);
-                    consider(t, S.sph_ids[i * 2 + 1], S.sph_ids[i * 2], i);
+                // Solid::Sphere (core.rs:183-195), four at a time: the discriminants are evaluated together (their
+                // operands are loaded together), then the few spheres the ray meets take the root, in scene order
+                for (uint32_t i0 = 0; i0 < S.n_spheres; i0 += 4u) {
+                    double disc[4], bb[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t i = min(i0 + u, S.n_spheres - 1u);  // (a batch past the end repeats the last sphere, unused)
+                        const double cx = sph_c[i * 4u], cy = sph_c[i * 4u + 1u], cz = sph_c[i * 4u + 2u], r = sph_c[i * 4u + 3u];
+                        const V3 oc = o - mk(cx, cy, cz);
+                        bb[u] = 2.0 * dot(dir, oc);
+                        const double c = dot(oc, oc) - r * r;
+                        disc[u] = bb[u] * bb[u] - 4.0 * a * c;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t i = i0 + u;
+                        if (i < S.n_spheres) {
+                            if (STATS) cnt.v[C_SPHERE]++;
+                            if (!(disc[u] < 0.0)) {
+                                const double t = (-bb[u] - __builtin_sqrt(disc[u])) / (2.0 * a);
+                                consider(t, sph_ids_c[i * 2 + 1], sph_ids_c[i * 2], i);
+                            }
+                        }
+                    }
                 }
                 for (uint32_t i = 0; i < S.n_planes; ++i) {
                     if (STATS) cnt.v[C_PLANE]++;
-                    const double* pp = S.planes + (size_t)i * 4;
+                    const cptr<double> pp = pl_c + (size_t)i * 4;
                     const V3 pn = ld3(pp);
                     const double dv = dot(pn, dir);
                     if (fabs(dv) < kEps) continue;
                     const V3 center = pn * pp[3];
                     const double t = dot(center - o, pn) / dv;
                     if (t < kEps) continue;
-                    consider(t, S.pl_ids[i * 2 + 1], S.pl_ids[i * 2], (1u << 30) | i);
+                    consider(t, pl_ids_c[i * 2 + 1], pl_ids_c[i * 2], (1u << 30) | i);
                 }
                 if (j == 0u) {
                     ba0 = best;
@@ -411,7 +431,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 if (found) fl |= FB_FOUND0 << j;
                 {
                     for (uint32_t m = 0; m < S.n_models && !item; ++m) {
-                        const RtmDevModel& M = S.models[m];
+                        const __attribute__((address_space(4))) RtmDevModel& M = models_c[m];
                         if (STATS) cnt.v[C_BBOX]++;
                         const double fx = 1.0 / dir.x, fy = 1.0 / dir.y, fz = 1.0 / dir.z;
                         const double t1 = (M.bmin[0] - o.x) * fx, t2 = (M.bmax[0] - o.x) * fx;
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         // ---- rays that have left a model and have further models to visit (scenes with several models)
         if (__ballot(st == TS_ENTER)) {
             for (uint32_t m = 0; m < S.n_models; ++m) {
-                const RtmDevModel& M = S.models[m];
+                const __attribute__((address_space(4))) RtmDevModel& M = as_const(S.models)[m];  // (wave-uniform: scalar loads)
                 if (st == TS_ENTER && model_i == m) {
                     if (STATS) cnt.v[C_BBOX]++;
                     const double fx = 1.0 / d.x, fy = 1.0 / d.y, fz = 1.0 / d.z;
