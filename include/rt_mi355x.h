@@ -10,7 +10,11 @@
  *
  * All entry points return 0 on success and a negative rtm_status on error; the message is
  * available from rtm_last_error().  Nothing unwinds across this boundary.  Single caller
- * thread per process (the reference renders once from main(), main.rs:158); not re-entrant.
+ * thread per process (the reference renders once from main(), main.rs:158); not re-entrant: a second thread
+ * entering a render entry point while another is inside gets RTM_ERR_STATE.  One frame is in flight at a time:
+ * the library keeps one work space and one set of internal streams per process, so a frame queued on any stream
+ * starts on the device only after the previous frame's last kernel (an event orders them; frames on different
+ * caller streams do not overlap, they do not corrupt each other either).
  */
 #ifndef RT_MI355X_H
 #define RT_MI355X_H
@@ -29,7 +33,7 @@ typedef enum rtm_status {
     RTM_ERR_DEVICE = -2,    /* HIP runtime error (no GPU, out of memory, launch failure) */
     RTM_ERR_PARSE = -3,     /* front end: scene text error, carries "msg at line:col" (parser.rs:43-75) */
     RTM_ERR_IO = -4,        /* front end: file could not be read ("Cannot load model", parser.rs:415-420) */
-    RTM_ERR_STATE = -5      /* rtm_init not called / handle already freed */
+    RTM_ERR_STATE = -5      /* rtm_init not called / handle already freed / another thread is inside a render call */
 } rtm_status;
 
 /* Camera fields of camera.rs:4-10 (private in the reference: the FFI crate adds accessors). */
@@ -112,7 +116,8 @@ typedef struct rtm_scene_dev rtm_scene_dev; /* opaque: a scene resident in HBM *
 uint32_t rtm_local_rows(const rtm_params* p);
 
 /* Select the HIP device of this process (one process per GPU).  device < 0: use LOCAL_RANK or 0.
- * No counterpart in the reference (it has no device). */
+ * Calling it again with another device releases what the library held on the old one (work space, streams, events);
+ * free the scenes uploaded there first.  No counterpart in the reference (it has no device). */
 int rtm_init(int device);
 int rtm_shutdown(void);
 const char* rtm_last_error(void);

@@ -153,6 +153,13 @@ def init(device: int = -1):
     _inited = True
 
 
+def shutdown():
+    """rtm_shutdown: frees the work space, internal streams and events (scenes must be released first)."""
+    global _inited
+    _check(_lib.rtm_shutdown())
+    _inited = False
+
+
 def set_tuning(key: str, value: int):
     """rtm_set_tuning: scheduling knobs of the device path (results never change)."""
     _lib.rtm_set_tuning.argtypes = [C.c_char_p, C.c_longlong]

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,13 @@ struct FrontWorkspace {  // rt_front.h path state and queues; grow-only, one per
     size_t bytes = 0;
 };
 static FrontWorkspace g_front_ws;
+// One frame at a time uses the process-wide state above (work space, internal streams, fork/join events, the wave kernel's
+// tile counter).  Frames queued from different caller streams are ordered by g_frame_done (recorded on the caller's stream
+// behind a frame's last kernel, waited for by the next frame's first); a second host thread entering a render entry point
+// while another is inside gets RTM_ERR_STATE.
+static std::atomic<bool> g_render_busy{false};
+static hipEvent_t g_frame_done = nullptr;
+static bool g_frame_done_valid = false;
 static size_t g_front_max_paths = 32u << 20;  // paths per band (668 B of workspace each); env RTM_FRONT_MAX_PATHS
 static uint32_t g_s_threshold = 24, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
@@ -271,6 +279,37 @@ uint32_t rtm_local_rows(const rtm_params* p) {
     return (p->height - p->row_begin + p->row_stride - 1) / p->row_stride;
 }
 
+// Everything the library holds on the current device (work space, streams, events, counters).  Used by rtm_shutdown
+// and by rtm_init when the process moves to another device: none of it may follow to the new one.
+static void release_device_state() {
+    if (g_device >= 0) (void)hipSetDevice(g_device);
+    if (g_frame_done_valid) (void)hipEventSynchronize(g_frame_done);
+    if (g_work_counter) (void)hipFree(g_work_counter);
+    g_work_counter = nullptr;
+    if (g_front_fork) {
+        (void)hipEventDestroy(g_front_fork);
+        g_front_fork = nullptr;
+        for (int i = 0; i < kFrontStreamsMax; ++i) {
+            (void)hipStreamDestroy(g_front_stream[i]);
+            (void)hipEventDestroy(g_front_join[i]);
+            g_front_stream[i] = nullptr;
+            g_front_join[i] = nullptr;
+        }
+    }
+    if (g_frame_done) (void)hipEventDestroy(g_frame_done);
+    g_frame_done = nullptr;
+    g_frame_done_valid = false;
+    for (auto& pr : g_front_ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    g_front_ev_pool.clear();
+    g_front_ev_used = 0;
+    if (g_front_ws.base) (void)hipFree(g_front_ws.base);
+    g_front_ws.base = nullptr;
+    g_front_ws.bytes = 0;
+}
+
 int rtm_init(int device) {
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
@@ -280,9 +319,11 @@ int rtm_init(int device) {
         device = lr ? std::atoi(lr) % count : 0;
     }
     if (device >= count) return rtm_internal_fail(RTM_ERR_INVALID, "device index out of range");
+    if (g_device >= 0 && g_device != device) release_device_state();  // (scenes uploaded to the old device stay there: free them first)
     HIP_TRY(hipSetDevice(device));
     g_device = device;
     if (!g_work_counter) HIP_TRY(hipMalloc((void**)&g_work_counter, 256));
+    if (!g_frame_done) HIP_TRY(hipEventCreateWithFlags(&g_frame_done, hipEventDisableTiming));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -328,25 +369,7 @@ int rtm_set_tuning(const char* key, long long value) {
 }
 
 int rtm_shutdown(void) {
-    if (g_work_counter) (void)hipFree(g_work_counter);
-    g_work_counter = nullptr;
-    if (g_front_fork) {
-        (void)hipEventDestroy(g_front_fork);
-        g_front_fork = nullptr;
-        for (int i = 0; i < kFrontStreamsMax; ++i) {
-            (void)hipStreamDestroy(g_front_stream[i]);
-            (void)hipEventDestroy(g_front_join[i]);
-        }
-    }
-    for (auto& pr : g_front_ev_pool) {
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
-    }
-    g_front_ev_pool.clear();
-    g_front_ev_used = 0;
-    if (g_front_ws.base) (void)hipFree(g_front_ws.base);
-    g_front_ws.base = nullptr;
-    g_front_ws.bytes = 0;
+    release_device_state();
     g_device = -1;
     return RTM_OK;
 }
@@ -538,32 +561,65 @@ __global__ void front_sum_items_kernel(const uint32_t* ctr, uint32_t nq, unsigne
     if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out, v);
 }
 
+struct FrontFixedWs {  // a work space that is already there, of fixed size: nothing is
+    char* base;        // allocated, the chunks of the frame run one after the other on the caller's stream, no events
+    size_t bytes;
+};
+
+struct FrontLayout {  // byte offsets of the work space of one chunk
+    size_t o_D0, o_D1, o_U0, o_U1, o_fin, o_res, o_itD, o_itU, o_ctr, bytes;
+};
+FrontLayout front_layout(size_t np_max, uint32_t nq) {
+    FrontLayout L{};
+    const uint32_t blocks_max = (uint32_t)((np_max + 63) / 64);
+    const uint32_t cap_l_max = ((blocks_max + nq - 1) / nq) * 64u;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t items_max = (size_t)nq * cap_l_max * 3u;
+    const size_t slots_max = (size_t)nq * cap_l_max;  // path slots (>= np_max: every wave's share is rounded up to whole blocks)
+    L.o_D0 = take(slots_max * rtf::PF_COUNT * 8); L.o_D1 = take(slots_max * rtf::PF_COUNT * 8);
+    L.o_U0 = take(slots_max * rtf::PU_COUNT * 4); L.o_U1 = take(slots_max * rtf::PU_COUNT * 4);
+    L.o_fin = take(slots_max * 3 * 8); L.o_res = take(slots_max * 3 * sizeof(rtf::FrontResult));
+    L.o_itD = take(items_max * rtf::IT_DCOUNT * 8); L.o_itU = take(items_max * rtf::IU_COUNT * 4);
+    L.o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
+    L.bytes = (off + 4095) & ~(size_t)4095;
+    return L;
+}
+
 int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, uint32_t occ_words, double* d_rgb, uint32_t* d_obj,
-                 uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof = nullptr) {
+                 uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof = nullptr,
+                 const FrontFixedWs* fixed = nullptr) {
     const bool stats = d_cnt != nullptr;
+    int mark_rc = RTM_OK;
     auto mark = [&](int kind, bool end, hipStream_t on) {  // event before / after a launch (profile runs only)
+        auto ok = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && mark_rc == RTM_OK) mark_rc = rtm_internal_fail(RTM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+            return e == hipSuccess;
+        };
+        if (fixed) return;
         if (!prof && g_front_timed_events && kind == 1) {
             if (!end) {
                 if (g_front_ev_used == g_front_ev_pool.size()) {
                     hipEvent_t a = nullptr, b = nullptr;
-                    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+                    if (!ok(hipEventCreate(&a), "hipEventCreate")) return;
+                    if (!ok(hipEventCreate(&b), "hipEventCreate")) { (void)hipEventDestroy(a); return; }
                     g_front_ev_pool.push_back({a, b});
                 }
-                (void)hipEventRecord(g_front_ev_pool[g_front_ev_used].first, on);
+                ok(hipEventRecord(g_front_ev_pool[g_front_ev_used].first, on), "hipEventRecord");
             } else if (g_front_ev_used < g_front_ev_pool.size()) {
-                (void)hipEventRecord(g_front_ev_pool[g_front_ev_used++].second, on);
+                ok(hipEventRecord(g_front_ev_pool[g_front_ev_used++].second, on), "hipEventRecord");
             }
             return;
         }
         if (!prof || prof->keep_cull) return;
         if (!end) {
-            hipEvent_t a, b;
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
+            hipEvent_t a = nullptr, b = nullptr;
+            if (!ok(hipEventCreate(&a), "hipEventCreate")) return;
+            if (!ok(hipEventCreate(&b), "hipEventCreate")) { (void)hipEventDestroy(a); return; }
             prof->ev[kind].push_back({a, b});
-            (void)hipEventRecord(a, on);
-        } else {
-            (void)hipEventRecord(prof->ev[kind].back().second, on);
+            ok(hipEventRecord(a, on), "hipEventRecord");
+        } else if (!prof->ev[kind].empty()) {
+            ok(hipEventRecord(prof->ev[kind].back().second, on), "hipEventRecord");
         }
     };
     const uint32_t tiles_x = (p->width + 7) / 8;
@@ -572,32 +628,37 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t bands_total = (n_rows + 7) / 8;
     // The frame is cut into chunks of whole 8-row bands; chunk c runs on internal stream c % n_conc with its own work space,
     // so the late rounds of one chunk (few paths alive: launch- and latency-bound) overlap the heavy rounds of another.
-    const uint32_t n_conc = std::max<uint32_t>(1, std::min<uint32_t>({g_front_streams, (uint32_t)kFrontStreamsMax, bands_total}));
+    const uint32_t n_conc = fixed ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({g_front_streams, (uint32_t)kFrontStreamsMax, bands_total}));
     uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / n_conc / band_paths);
     bands_per_chunk = std::min(bands_per_chunk, (bands_total + n_conc - 1) / n_conc);
+    // sub-queues (rt_front.h): the shade grid has exactly nq waves, one sub-list per shade wave.  (The fixed work space
+    // uses a third of them: every sub-queue owns whole 64-path blocks, which is what a small work space is spent on.)
+    const uint32_t nq = (uint32_t)g_num_cus * (fixed ? 8u : g_front_shade_waves_per_cu);
+    if (fixed) {  // as many bands at a time as the work space holds
+        while (bands_per_chunk > 1 && front_layout(band_paths * bands_per_chunk, nq).bytes > fixed->bytes) --bands_per_chunk;
+        if (front_layout(band_paths * bands_per_chunk, nq).bytes > fixed->bytes)
+            return rtm_internal_fail(RTM_ERR_INVALID, "frame too wide for the static scratch: one 8-row band of width x spp = " +
+                                                          std::to_string((unsigned long long)p->width * p->spp) + " sample paths per row needs " +
+                                                          std::to_string(front_layout(band_paths, nq).bytes >> 20) + " MiB of " +
+                                                          std::to_string(fixed->bytes >> 20) + " MiB (lower width or spp, or use rtm_render_device)");
+    }
     const size_t np_max = band_paths * bands_per_chunk;
     if (np_max + (size_t)64 * 64 * 1024 >= (1ull << 30)) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
-    // sub-queues (rt_front.h): the shade grid is a multiple of nq waves
-    const uint32_t nq = (uint32_t)g_num_cus * g_front_shade_waves_per_cu;  // one sub-list per shade wave
-    const uint32_t blocks_max = (uint32_t)((np_max + 63) / 64);
-    const uint32_t cap_l_max = ((blocks_max + nq - 1) / nq) * 64u;
-    // workspace layout (all sized for np_max)
-    size_t off = 0;
-    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-    const size_t items_max = (size_t)nq * cap_l_max * 3u;
-    const size_t slots_max = (size_t)nq * cap_l_max;  // path slots (>= np_max: every wave's share is rounded up to whole blocks)
-    const size_t o_D0 = take(slots_max * rtf::PF_COUNT * 8), o_D1 = take(slots_max * rtf::PF_COUNT * 8);
-    const size_t o_U0 = take(slots_max * rtf::PU_COUNT * 4), o_U1 = take(slots_max * rtf::PU_COUNT * 4);
-    const size_t o_fin = take(slots_max * 3 * 8), o_res = take(slots_max * 3 * sizeof(rtf::FrontResult));
-    const size_t o_itD = take(items_max * rtf::IT_DCOUNT * 8), o_itU = take(items_max * rtf::IU_COUNT * 4);
-    const size_t o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
-    const size_t ws_one = (off + 4095) & ~(size_t)4095;
-    if (ws_one * n_conc > g_front_ws.bytes) {
-        if (g_front_ws.base) HIP_TRY(hipFree(g_front_ws.base));
-        g_front_ws.base = nullptr;
-        g_front_ws.bytes = 0;
-        HIP_TRY(hipMalloc((void**)&g_front_ws.base, ws_one * n_conc));
-        g_front_ws.bytes = ws_one * n_conc;
+    const FrontLayout L = front_layout(np_max, nq);
+    const size_t o_D0 = L.o_D0, o_D1 = L.o_D1, o_U0 = L.o_U0, o_U1 = L.o_U1, o_fin = L.o_fin, o_res = L.o_res, o_itD = L.o_itD,
+                 o_itU = L.o_itU, o_ctr = L.o_ctr, ws_one = L.bytes;
+    char* ws_base = fixed ? fixed->base : nullptr;
+    if (!fixed) {
+        if (ws_one * n_conc > g_front_ws.bytes) {
+            // (frames queued earlier, on whatever stream, may still be using the old work space)
+            if (g_frame_done_valid) HIP_TRY(hipEventSynchronize(g_frame_done));
+            if (g_front_ws.base) HIP_TRY(hipFree(g_front_ws.base));
+            g_front_ws.base = nullptr;
+            g_front_ws.bytes = 0;
+            HIP_TRY(hipMalloc((void**)&g_front_ws.base, ws_one * n_conc));
+            g_front_ws.bytes = ws_one * n_conc;
+        }
+        ws_base = g_front_ws.base;
     }
     // fork: the internal streams start after whatever the caller queued on `stream`
     hipStream_t lanes[kFrontStreamsMax];
@@ -619,7 +680,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk, ++chunk) {
         const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
         hipStream_t stream = lanes[chunk % n_conc];                            // (shadows the caller's stream inside the loop)
-        char* const B = g_front_ws.base + (size_t)(chunk % n_conc) * ws_one;
+        char* const B = ws_base + (size_t)(chunk % n_conc) * ws_one;
         rtf::FrontArgs A{};
         A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_bounces = p->max_bounces; A.seed = p->seed;
         A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
@@ -660,7 +721,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 mark(1, true, stream);
             }
             HIP_TRY(hipGetLastError());
-            if (g_front_debug_rounds) {  // RTM_FRONT_DEBUG_ROUNDS=1: list lengths after every round (synchronises; diagnostics only)
+            if (g_front_debug_rounds && !fixed) {  // RTM_FRONT_DEBUG_ROUNDS=1: list lengths after every round (synchronises; diagnostics only)
                 std::vector<uint32_t> h((size_t)nq * rtf::CT_STRIDE);
                 HIP_TRY(hipStreamSynchronize(stream));
                 HIP_TRY(hipMemcpy(h.data(), A.ctr, h.size() * 4, hipMemcpyDeviceToHost));
@@ -701,8 +762,28 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             HIP_TRY(hipStreamWaitEvent(stream, g_front_join[i], 0));
         }
     }
-    return RTM_OK;
+    return mark_rc;
 }
+
+// Entry and exit of every call that uses the process-wide device state (see g_render_busy): one host thread at a time;
+// the frame starts after the previous frame's last kernel, whatever stream that was queued on.
+struct FrameGuard {
+    bool owned = false;
+    int enter(hipStream_t stream) {
+        if (g_render_busy.exchange(true)) return rtm_internal_fail(RTM_ERR_STATE, "another thread is inside a render call (the library is not re-entrant)");
+        owned = true;
+        if (g_frame_done_valid) HIP_TRY(hipStreamWaitEvent(stream, g_frame_done, 0));
+        return RTM_OK;
+    }
+    int leave(hipStream_t stream) {
+        HIP_TRY(hipEventRecord(g_frame_done, stream));
+        g_frame_done_valid = true;
+        return RTM_OK;
+    }
+    ~FrameGuard() {
+        if (owned) g_render_busy.store(false);
+    }
+};
 }  // namespace
 
 int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, uint32_t* d_obj, uint32_t* d_tri,
@@ -731,6 +812,8 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     const uint32_t wgs_per_cu = wgs_env ? wgs_env : (uint32_t)RTM_WAVE_OCC;
     const uint32_t wave_wgs = std::min<uint32_t>((AW.n_tiles + 3) / 4, (uint32_t)g_num_cus * wgs_per_cu);
     const bool front = !v1 && !(p->flags & RTM_FLAG_KERNEL_WAVE) && g_kernel == 2 && front_supported(sd, p);
+    FrameGuard guard;
+    if (int rc = guard.enter(stream)) return rc;
     int front_rc = RTM_OK;
     auto launch = [&](bool stats, unsigned long long* d_cnt) {
         if (front) {
@@ -759,6 +842,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         (void)hipFree(d_cnt);
         if (front_rc != RTM_OK) return front_rc;
         if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("render (stats): ") + hipGetErrorString(e));
+        if (int rc = guard.leave(stream)) return rc;
         if (std::getenv("RTM_DIAG") && front && h[22])
             std::fprintf(stderr, "[rtm diag front] trace waves %llu: mean %.0f cycles, sum of per-launch max not tracked; max single wave %llu cycles; total wave-cycles %.3g: refill %.1f%% (%.0f/refill)  walk %.1f%% (%.0f/iter)  test %.1f%% (%.0f/step)\n",
                          h[22], (double)h[20] / (double)h[22], h[21] >> 24, (double)h[20], 100.0 * h[23] / (double)h[20], h[15] ? (double)h[23] / h[15] : 0.0,
@@ -788,7 +872,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         if (front_rc != RTM_OK) return front_rc;
         HIP_TRY(e);
     }
-    return RTM_OK;
+    return guard.leave(stream);
 }
 
 int rtm_time_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, int iters, void* stream_, double* out_ms) {
@@ -833,6 +917,8 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
         return RTM_OK;
     }
     const uint32_t occ_words = front_occ_words(sd);
+    FrameGuard guard;
+    if (int rc = guard.enter(stream)) return rc;
     unsigned long long* d_buf = nullptr;  // [0..31] counters of the counting run, [32] traced rays
     HIP_TRY(hipMalloc((void**)&d_buf, 40 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(d_buf, 0, 40 * sizeof(unsigned long long), stream));
@@ -866,7 +952,7 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
     (void)hipFree(d_buf);
     if (rc != RTM_OK) return rc;
     if (e != hipSuccess) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("profile: ") + hipGetErrorString(e));
-    return RTM_OK;
+    return guard.leave(stream);
 }
 
 int rtm_timed_events_collect(double* out_trace_ms, uint32_t* out_trace_launches) {

@@ -220,6 +220,38 @@ def test_device_entry_points_and_tonemap(rtm_gpu, rtm_scene, orc):
     assert d.max() <= 1  # powf on device vs libm: not bit-pinned, at most one code value (main.rs:42-48)
 
 
+def test_two_caller_streams_do_not_corrupt_each_other(rtm_gpu, rtm_scene):
+    """rtm_render_device is asynchronous and the library keeps ONE work space and one set of internal streams: frames
+    queued back to back on different caller streams (no host synchronisation in between) are ordered by the library's
+    frame-done event; different sizes make the work-space layouts of the two frames differ, and the second frame is
+    large enough to regrow the work space while the first may still be queued."""
+    import torch
+    s, t = rtm_scene("bunny"), rtm_scene("suzanne")
+    pa, pb = rtm_gpu.make_params(96, 64, spp=4, seed=2), rtm_gpu.make_params(320, 200, spp=6, seed=3)
+    ref_a = s.render(spp=4, seed=2, width=96, height=64)["rgb"]
+    ref_b = t.render(spp=6, seed=3, width=320, height=200)["rgb"]
+    rtm_gpu.shutdown()  # drop the work space so that the frames below have to grow it
+    rtm_gpu.init(0)
+    for rel in (s, t):
+        rel.release_device()
+    try:
+        for streams in (1, 2):
+            rtm_gpu.set_tuning("front_streams", streams)
+            sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            a = [torch.empty(64, 96, 3, dtype=torch.float64, device="cuda") for _ in range(3)]
+            b = [torch.empty(200, 320, 3, dtype=torch.float64, device="cuda") for _ in range(3)]
+            torch.cuda.synchronize()
+            for i in range(3):
+                s.render_device(pa, a[i].data_ptr(), stream=sa.cuda_stream)
+                t.render_device(pb, b[i].data_ptr(), stream=sb.cuda_stream)
+            torch.cuda.synchronize()
+            for i in range(3):
+                assert np.array_equal(a[i].cpu().numpy(), ref_a), f"streams={streams} frame a{i}"
+                assert np.array_equal(b[i].cpu().numpy(), ref_b), f"streams={streams} frame b{i}"
+    finally:
+        rtm_gpu.set_tuning("front_streams", 2)
+
+
 def test_edge_cases(rtm_gpu, orc):
     """Empty scene, no lights, ragged tiles, one bounce, single pixel."""
     for txt, kw in (("size 20 13", {}),                                        # nothing to hit: sky (main.rs:127)
