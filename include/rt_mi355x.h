@@ -153,6 +153,22 @@ int rtm_scene_free(rtm_scene_dev* scene);
  * stream is a hipStream_t (NULL = default stream).  Asynchronous unless out_stats != NULL. */
 int rtm_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, uint32_t* d_obj_id,
                       uint32_t* d_tri_id, rtm_stats* out_stats, void* stream);
+/* rtm_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  Same kernels and same bits as rtm_render_device's
+ * default (ray-front) path, but their work space -- path state, query results, ray items, sub-queue counters -- is a
+ * static device array of rtm_noalloc_scratch_bytes() = 256 MiB that every GPU the library runs on holds until the
+ * process ends, instead of hipMalloc'ed memory; the call makes no hipMalloc/hipFree and creates no stream or event:
+ * it only launches kernels on `stream`.  The frame is rendered in groups of 8-row bands that fit the array; a frame
+ * whose single band does not fit (about width x spp > 32 Ki sample paths per row: e.g. 1200 wide up to 27 spp, 3840 wide
+ * up to 8 spp) is rejected with RTM_ERR_INVALID and a message that states the need.  No out_stats, no
+ * RTM_FLAG_KERNEL_* (RTM_ERR_INVALID); scenes beyond the ray-front pipeline's limits are rejected, not rerouted.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams, or a captured
+ * graph replayed while another call runs) RACE and corrupt each other's frames -- serialise them; the array keeps the
+ * last call's contents and the kernels rewrite every word before reading it, so nothing needs clearing. */
+int rtm_render_device_noalloc(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, uint32_t* d_obj_id,
+                              uint32_t* d_tri_id, void* stream);
+uint64_t rtm_noalloc_scratch_bytes(void);
+
 /* Average device time (ms, HIP events on `stream`) of `iters` back-to-back rtm_render_device launches. */
 int rtm_time_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, int iters,
                            void* stream, double* out_ms_avg);

@@ -102,6 +102,8 @@ _lib.rtm_render.argtypes = [C.POINTER(RtmScene), C.POINTER(RtmParams), _vp, _vp,
 _lib.rtm_scene_upload.argtypes = [C.POINTER(RtmScene), C.POINTER(_vp)]
 _lib.rtm_scene_free.argtypes = [_vp]
 _lib.rtm_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, _vp, _vp, C.POINTER(RtmStats), _vp]
+_lib.rtm_render_device_noalloc.argtypes = [_vp, C.POINTER(RtmParams), _vp, _vp, _vp, _vp]
+_lib.rtm_noalloc_scratch_bytes.restype = C.c_uint64
 _lib.rtm_time_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, C.c_int, _vp, C.POINTER(C.c_double)]
 _lib.rtm_profile_render_device.argtypes = [_vp, C.POINTER(RtmParams), _vp, _vp, C.POINTER(RtmProfile)]
 _lib.rtm_trace_rays.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
@@ -123,7 +125,8 @@ EXPORTED_SYMBOLS = (
     "rtm_local_rows", "rtm_init", "rtm_shutdown", "rtm_last_error", "rtm_version", "rtm_set_tuning", "rtm_render", "rtm_scene_upload",
     "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_profile_render_device", "rtm_trace_rays", "rtm_tonemap_device",
     "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
-    "rtm_frontend_size", "rtm_frontend_free", "rtm_render_rgb8", "rtm_write_bmp", "rtm_cli_main", "rtm_timed_events_collect")
+    "rtm_frontend_size", "rtm_frontend_free", "rtm_render_rgb8", "rtm_write_bmp", "rtm_cli_main", "rtm_timed_events_collect",
+    "rtm_render_device_noalloc", "rtm_noalloc_scratch_bytes")
 
 
 def raw_lib() -> C.CDLL:
@@ -158,6 +161,10 @@ def shutdown():
     global _inited
     _check(_lib.rtm_shutdown())
     _inited = False
+
+
+def noalloc_scratch_bytes() -> int:
+    return int(_lib.rtm_noalloc_scratch_bytes())
 
 
 def set_tuning(key: str, value: int):
@@ -291,6 +298,11 @@ class Scene:
         _check(_lib.rtm_render_device(self.device_handle(), C.byref(params), d_rgb, d_obj or None, d_tri or None,
                                       C.byref(st) if stats else None, stream or None))
         return st.as_dict() if stats else None
+
+    def render_device_noalloc(self, params: RtmParams, d_rgb: int, d_obj: int = 0, d_tri: int = 0, stream: int = 0):
+        """rtm_render_device_noalloc: the same frame out of the library's static scratch array; allocates nothing."""
+        _check(_lib.rtm_render_device_noalloc(self.device_handle(), C.byref(params), d_rgb, d_obj or None, d_tri or None,
+                                              stream or None))
 
     def time_render_device(self, params: RtmParams, d_rgb: int, iters: int, stream: int = 0) -> float:
         ms = C.c_double()

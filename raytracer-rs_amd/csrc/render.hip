@@ -37,6 +37,9 @@ static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile 
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
 static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); env RTM_KERNEL=wave|front
+#ifndef RTM_NOALLOC_SCRATCH_MIB
+#define RTM_NOALLOC_SCRATCH_MIB 256  // size of the static work space of rtm_render_device_noalloc
+#endif
 constexpr int kFrontStreamsMax = 4;
 static uint32_t g_front_streams = 2;  // chunks of a frame in flight at once; env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
 static hipStream_t g_front_stream[kFrontStreamsMax] = {};
@@ -279,6 +282,8 @@ uint32_t rtm_local_rows(const rtm_params* p) {
     return (p->height - p->row_begin + p->row_stride - 1) / p->row_stride;
 }
 
+static int scratch_bind(int device);  // (defined beside the scratch array, further down)
+
 // Everything the library holds on the current device (work space, streams, events, counters).  Used by rtm_shutdown
 // and by rtm_init when the process moves to another device: none of it may follow to the new one.
 static void release_device_state() {
@@ -324,6 +329,7 @@ int rtm_init(int device) {
     g_device = device;
     if (!g_work_counter) HIP_TRY(hipMalloc((void**)&g_work_counter, 256));
     if (!g_frame_done) HIP_TRY(hipEventCreateWithFlags(&g_frame_done, hipEventDisableTiming));
+    if (int rc = scratch_bind(device)) return rc;
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -561,7 +567,7 @@ __global__ void front_sum_items_kernel(const uint32_t* ctr, uint32_t nq, unsigne
     if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out, v);
 }
 
-struct FrontFixedWs {  // a work space that is already there, of fixed size: nothing is
+struct FrontFixedWs {  // rtm_render_device_noalloc: a work space that is already there (the static scratch array); nothing is
     char* base;        // allocated, the chunks of the frame run one after the other on the caller's stream, no events
     size_t bytes;
 };
@@ -873,6 +879,45 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
         HIP_TRY(e);
     }
     return guard.leave(stream);
+}
+
+// ---- the entry point that allocates nothing ----------------------------------------------------------------------
+// The work space of the ray-front pipeline (path state, query results, ray items, sub-queue counters: rt_front.h) in a
+// static device array instead of hipMalloc'ed memory.  Each GPU the library runs on holds its own copy, at its own
+// address, until the process ends; rtm_init asks for that address once per device (the array's NAME is only a host-side
+// stand-in for the symbol and is never handed to a kernel or a memset).
+constexpr size_t kStaticScratchBytes = (size_t)RTM_NOALLOC_SCRATCH_MIB << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+static char* g_scratch_ptr[kMaxDevices] = {};  // per device: where that device's copy of `scratch` lives
+
+static int scratch_bind(int device) {
+    if (device < 0 || device >= kMaxDevices) return rtm_internal_fail(RTM_ERR_INVALID, "device index beyond the library's table of devices");
+    if (g_scratch_ptr[device]) return RTM_OK;
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));  // (the current device is `device`: rtm_init has just selected it)
+    if (e != hipSuccess || !ptr) return rtm_internal_fail(RTM_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    g_scratch_ptr[device] = (char*)ptr;
+    return RTM_OK;
+}
+
+uint64_t rtm_noalloc_scratch_bytes(void) { return (uint64_t)kStaticScratchBytes; }
+
+int rtm_render_device_noalloc(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, uint32_t* d_obj, uint32_t* d_tri, void* stream_) {
+    if (int rc = need_init()) return rc;
+    if (!sd || !d_rgb) return rtm_internal_fail(RTM_ERR_INVALID, "scene or output is null");
+    if (int rc = check_params(p)) return rc;
+    if (p->flags & (RTM_FLAG_KERNEL_V1 | RTM_FLAG_KERNEL_WAVE)) return rtm_internal_fail(RTM_ERR_INVALID, "rtm_render_device_noalloc runs the ray-front pipeline only");
+    if (!front_supported(sd, p)) return rtm_internal_fail(RTM_ERR_INVALID, "scene or frame beyond the ray-front pipeline's limits (grid > 1023 cells per side, >= 2^26 list entries)");
+    if (sd->device != g_device || !g_scratch_ptr[g_device]) return rtm_internal_fail(RTM_ERR_STATE, "scene was uploaded to another device, or rtm_init has not bound the scratch array");
+    if (g_render_busy.exchange(true)) return rtm_internal_fail(RTM_ERR_STATE, "another thread is inside a render call (the library is not re-entrant)");
+    const FrontFixedWs ws{g_scratch_ptr[g_device], kStaticScratchBytes};
+    // Only kernel launches from here on: no allocation, no event, no memset (every counter word the kernels read is
+    // written by the shade kernel of the same round; the scratch keeps the last call's contents and none of them is read
+    // before it is rewritten).
+    const int rc = render_front(sd, p, rtm_local_rows(p), front_occ_words(sd), d_rgb, d_obj, d_tri, nullptr, (hipStream_t)stream_, nullptr, &ws);
+    g_render_busy.store(false);
+    return rc;
 }
 
 int rtm_time_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rgb, int iters, void* stream_, double* out_ms) {
