@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -203,6 +204,9 @@ struct rtm_scene_dev {
     std::vector<uint32_t> occ_words;  // per model: words of its cell-occupancy bitmap
     uint32_t max_n = 0;               // largest cells_per_side
     uint64_t max_list = 0;            // largest n_tri_idx
+    uint64_t n_long_cells = 0;        // cells with more than 32 entries, over all models
+    uint32_t occ7_words = 0;          // words of the seven scene-wide bitmaps (rt_front.h)
+    bool front_ok = true;             // the scene fits the packed indices of the ray-front path
     int device;
 };
 
@@ -429,6 +433,14 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
         return fail(rc);
 
     std::vector<RtmDevModel> models(s->n_models);
+    // The ray-front path's view of the grids (rt_front.h): ONE array of cell records, list records, boxes, frames and
+    // bitmaps over the cells of all models (model m's cells start at cell_base, a multiple of 32; list positions are global),
+    // so that the lanes of a wave traverse whichever model their ray is in side by side -- what differs per model is one
+    // word of per-lane state (cells per side, cell_base), not a set of wave-uniform pointers.
+    std::vector<double> g_rec, g_frames;
+    std::vector<uint32_t> g_info, g_box8;
+    std::vector<std::vector<uint32_t>> occ7_of_model;
+    uint64_t total_cells = 0;
     for (uint32_t m = 0; m < s->n_models; ++m) {
         const rtm_model& M = s->models[m];
         RtmDevModel& D = models[m];
@@ -464,14 +476,20 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             }
         // the lists again, as records in list order (rt_front.h): a cell's entries are contiguous 80-byte records, so the
         // traversal reads them without the indirection through tri_idx and neighbouring entries share cache lines
-        std::vector<double> rec((size_t)M.n_tri_idx * 10);
+        const uint64_t entry_base = g_rec.size() / 10, cell_base = total_cells;
+        if (entry_base + M.n_tri_idx >= 0xFFFFFFF0ull || cell_base + n3 >= (1ull << 27)) {
+            sd->front_ok = false;  // (beyond the packed indices of rt_front.h: the single-kernel formulation renders such scenes)
+        }
+        D.cell_base = (uint32_t)cell_base;
+        total_cells += (n3 + 31) & ~(size_t)31;
+        g_rec.resize((size_t)(entry_base + M.n_tri_idx) * 10);
+        double* const rec = g_rec.data() + (size_t)entry_base * 10;
         for (uint64_t e = 0; e < M.n_tri_idx; ++e) {
             const uint32_t t = idx[e];
             for (int a = 0; a < 9; ++a) rec[e * 10 + a] = pos[(size_t)t * 9 + a];
             const uint64_t bits = t;
             std::memcpy(&rec[e * 10 + 9], &bits, 8);
         }
-        if ((rc = upload(sd, rec, &D.cell_rec))) return fail(rc);
         // Per cell: [start, end) and, for lists of at most 32 entries, one mask per arrival direction.  The reference tests
         // every entry of every cell it visits; an entry whose triangle is also listed in the cell the DDA step came from
         // was tested one step earlier with the same ray and was not accepted (the walk would have ended there,
@@ -504,7 +522,62 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
                     info[c * 8 + 2 + a] = mask;
                 }
             }
-            if ((rc = upload(sd, info, &D.cell_info))) return fail(rc);
+            // Long cells (more than 32 entries: no arrival masks): every entry gets its triangle's bounding box, quantised to 8
+            // bits per coordinate in a frame of the cell -- the region that bounds all its triangles, mapped to [2, 253] --
+            // and rounded OUTWARDS by at least one quantum.  The trace kernel tests a ray against these 8-byte boxes before it
+            // reads an entry's 80-byte record: a ray whose line misses the enlarged box cannot pass the reference's
+            // triangle test (model.rs:43-74 accepts only points of the triangle, give or take rounding that is many orders
+            // below a quantum), so skipping the entry leaves every accepted hit, hence the result, unchanged.
+            {
+                std::vector<double>& frames = g_frames;
+                const size_t frames_before = frames.size();
+                g_box8.resize((size_t)(entry_base + M.n_tri_idx) * 2, 0u);
+                uint32_t* const box8 = g_box8.data() + (size_t)entry_base * 2;
+                for (size_t c = 0; c < n3; ++c) {
+                    const uint32_t b = start[c], e = start[c + 1];
+                    if (e - b <= 32u) continue;
+                    double rlo[3] = {1e300, 1e300, 1e300}, rhi[3] = {-1e300, -1e300, -1e300};
+                    auto tri_box = [&](uint32_t t, double lo[3], double hi[3]) {
+                        for (int a = 0; a < 3; ++a) {
+                            const double v0 = M.pos[a][t], v1 = M.pos[3 + a][t], v2 = M.pos[6 + a][t];
+                            lo[a] = std::min(v0, std::min(v1, v2));
+                            hi[a] = std::max(v0, std::max(v1, v2));
+                        }
+                    };
+                    for (uint32_t k = b; k < e; ++k) {
+                        double lo[3], hi[3];
+                        tri_box(idx[k], lo, hi);
+                        for (int a = 0; a < 3; ++a) { rlo[a] = std::min(rlo[a], lo[a]); rhi[a] = std::max(rhi[a], hi[a]); }
+                    }
+                    double ctr[3], iq[3];
+                    bool usable = true;
+                    for (int a = 0; a < 3; ++a) {
+                        const double ext = (rhi[a] - rlo[a]) * 1.001 + 1e-9 * (1.0 + std::fabs(rlo[a]) + std::fabs(rhi[a]));
+                        ctr[a] = 0.5 * (rlo[a] + rhi[a]);
+                        iq[a] = 251.0 / ext;
+                        usable = usable && std::isfinite(ctr[a]) && std::isfinite(iq[a]) && iq[a] > 0.0;
+                    }
+                    const uint32_t frame = (uint32_t)(frames.size() / 8);
+                    for (int a = 0; a < 3; ++a) frames.push_back(ctr[a]);
+                    for (int a = 0; a < 3; ++a) frames.push_back(iq[a]);
+                    frames.push_back(0.0); frames.push_back(0.0);
+                    info[c * 8 + 2] = frame;
+                    for (uint32_t k = b; k < e; ++k) {
+                        double lo[3], hi[3];
+                        tri_box(idx[k], lo, hi);
+                        uint32_t q0[3], q1[3];
+                        for (int a = 0; a < 3; ++a) {
+                            const double l = (lo[a] - ctr[a]) * iq[a] + 127.5, h = (hi[a] - ctr[a]) * iq[a] + 127.5;
+                            // (non-finite vertices, or a frame that cannot be formed: the whole range, i.e. never rejected)
+                            q0[a] = (usable && l >= 1.0 && l <= 255.0) ? (uint32_t)std::floor(l) - 1u : 0u;
+                            q1[a] = (usable && h >= 0.0 && h <= 254.0) ? (uint32_t)std::ceil(h) + 1u : 255u;
+                        }
+                        box8[(size_t)k * 2] = q0[0] | (q0[1] << 8) | (q0[2] << 16) | (q1[0] << 24);
+                        box8[(size_t)k * 2 + 1] = q1[1] | (q1[2] << 8);
+                    }
+                }
+                sd->n_long_cells += (frames.size() - frames_before) / 8;
+            }
             // ... and the same knowledge as bitmaps for the walk: arriving along direction a, a cell whose entries were all
             // tested one step earlier is as good as empty
             const size_t words = occ.size();
@@ -516,10 +589,28 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
                     if (len > 32 || info[c * 8 + 2 + a] != 0u) occ7[(size_t)a * words + (c >> 5)] |= 1u << (c & 31);
                 occ7[6 * words + (c >> 5)] |= 1u << (c & 31);
             }
-            if ((rc = upload(sd, occ7, &D.occupancy7))) return fail(rc);
+            occ7_of_model.push_back(std::move(occ7));
+            // into the scene-wide array: list positions become global
+            for (size_t c = 0; c < n3; ++c) { info[c * 8] += (uint32_t)entry_base; info[c * 8 + 1] += (uint32_t)entry_base; }
+            g_info.resize((size_t)total_cells * 8, 0u);
+            std::memcpy(g_info.data() + (size_t)cell_base * 8, info.data(), info.size() * 4);
         }
         if ((rc = upload(sd, start, &D.cell_start)) || (rc = upload(sd, idx, &D.tri_idx)) || (rc = upload(sd, pos, &D.tri_pos)) ||
             (rc = upload(sd, nrm, &D.tri_nrm)) || (rc = upload(sd, occ, &D.occupancy)))
+            return fail(rc);
+    }
+    {   // the seven bitmaps, each over the cells of all models
+        const size_t W = (size_t)(total_cells / 32);
+        std::vector<uint32_t> occ7_all(W * 7 + 1, 0u);
+        for (uint32_t m = 0; m < s->n_models; ++m) {
+            const size_t wm = occ7_of_model[m].size() / 7, wbase = models[m].cell_base / 32;
+            for (int a = 0; a < 7; ++a) std::memcpy(occ7_all.data() + (size_t)a * W + wbase, occ7_of_model[m].data() + (size_t)a * wm, wm * 4);
+        }
+        V.g_occ_dir_words = (uint32_t)W;
+        sd->occ7_words = (uint32_t)std::min<size_t>(W * 7, 0xFFFFFFFFu);
+        g_box8.resize(g_box8.size() + 8, 0u);
+        if ((rc = upload(sd, occ7_all, &V.g_occ7)) || (rc = upload(sd, g_info, &V.g_cell_info)) || (rc = upload(sd, g_rec, &V.g_cell_rec)) ||
+            (rc = upload(sd, g_frames, &V.g_cell_frame)) || (rc = upload(sd, g_box8, &V.g_cell_box8)))
             return fail(rc);
     }
     if ((rc = upload(sd, models, &V.models))) return fail(rc);
@@ -540,17 +631,13 @@ namespace {
 bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
     // packed cell coordinates and model indices (rt_front.h); one 8-row band of paths must fit the workspace budget
     const uint64_t band_paths = (uint64_t)((p->width + 7) / 8) * 64u * p->spp;
-    return sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && sd->max_list < rtf::kMaxListEntries && band_paths <= (64ull << 20);
+    return sd->front_ok && sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && band_paths <= (64ull << 20);
 }
 
-// words of the direction bitmaps (seven per model) that fit the trace kernel's LDS budget, models in order
+// words of the seven scene-wide bitmaps when they fit the trace kernel's LDS budget (all of them or none: a probe that
+// may go either way would wait for both memories)
 uint32_t front_occ_words(const rtm_scene_dev* sd) {
-    uint32_t words = 0;
-    for (uint32_t w : sd->occ_words) {
-        if (words + 7u * w > (uint32_t)rtw::kOccLdsWordsMax) break;
-        words += 7u * w;
-    }
-    return words;
+    return sd->occ7_words <= (uint32_t)rtw::kOccLdsWordsMax ? sd->occ7_words : 0u;
 }
 
 // One frame as bands of rows; per band: round 0 (camera rays), then shade/trace rounds until no path is alive.
@@ -679,9 +766,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t shade_wgs = nq / 4u;
     // (a small chunk's launches are latency-bound: three workgroups per CU leave room for the other chunk's waves; measured)
     const uint32_t trace_wgs = (uint32_t)g_num_cus * (g_front_trace_wgs_env ? g_front_trace_wgs_per_cu : (np_max >= ((size_t)8 << 20) ? (uint32_t)RTM_FRONT_OCC : 3u));
-    uint32_t occ_total = 0;
-    for (uint32_t w : sd->occ_words) occ_total += w;
-    const bool all_lds = occ_total * 7u == occ_words;  // every bitmap is staged in LDS
+    const bool all_lds = occ_words == sd->occ7_words;  // the bitmaps are staged in LDS
     uint32_t chunk = 0;
     for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk, ++chunk) {
         const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
@@ -717,12 +802,15 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             if (r + 1 < rounds) {  // the last round only finalises
                 mark(1, false, stream);
                 const size_t lds = (size_t)occ_words * 4;
-                if (stats) {
-                    if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<true, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
-                    else hipLaunchKernelGGL((rtf::front_trace_kernel<true, false>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
-                } else {
-                    if (all_lds) hipLaunchKernelGGL((rtf::front_trace_kernel<false, true>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
-                    else hipLaunchKernelGGL((rtf::front_trace_kernel<false, false>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt);
+                const int variant = (stats ? 4 : 0) | (all_lds ? 2 : 0) | (sd->n_long_cells ? 1 : 0);
+                switch (variant) {
+#define RTM_TRACE_CASE(v, S_, L_, G_) \
+    case v: hipLaunchKernelGGL((rtf::front_trace_kernel<S_, L_, G_>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt); break;
+                    RTM_TRACE_CASE(0, false, false, false) RTM_TRACE_CASE(1, false, false, true)
+                    RTM_TRACE_CASE(2, false, true, false) RTM_TRACE_CASE(3, false, true, true)
+                    RTM_TRACE_CASE(4, true, false, false) RTM_TRACE_CASE(5, true, false, true)
+                    RTM_TRACE_CASE(6, true, true, false) RTM_TRACE_CASE(7, true, true, true)
+#undef RTM_TRACE_CASE
                 }
                 mark(1, true, stream);
             }
@@ -857,6 +945,9 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
             std::fprintf(stderr, "[rtm diag front] test steps %llu (avg %.1f lanes)  walk iters %llu (avg %.1f lanes)  test slots %llu (avg %.1f lanes)  refills %llu (avg %.1f lanes)\n",
                          h[9], h[9] ? (double)h[10] / (double)h[9] : 0.0, h[11], h[11] ? (double)h[12] / (double)h[11] : 0.0, h[13],
                          h[13] ? (double)h[14] / (double)h[13] : 0.0, h[15], h[15] ? (double)h[16] / (double)h[15] : 0.0);
+        if (std::getenv("RTM_DIAG") && front && (h[9] + h[11]))
+            std::fprintf(stderr, "[rtm diag front] per step (walk or test), lanes on average: idle %.1f, in another state or model %.1f; testers waiting in a walk step %.1f, walkers waiting in a test step %.1f\n",
+                         (double)h[28] / (double)(h[9] + h[11]), (double)h[29] / (double)(h[9] + h[11]), h[11] ? (double)h[30] / (double)h[11] : 0.0, h[9] ? (double)h[31] / (double)h[9] : 0.0);
         if (std::getenv("RTM_DIAG") && !front && h[9])
             std::fprintf(stderr, "[rtm diag] S rounds %llu (avg %.1f lanes, %.0f cyc/round)  T steps %llu (avg %.1f lanes, %.0f cyc/step)  wave cycles: S %.1f%% T %.1f%% of %.3g\n",
                          h[9], (double)h[10] / (double)h[9], (double)h[13] / (double)h[9], h[11], h[11] ? (double)h[12] / (double)h[11] : 0.0,

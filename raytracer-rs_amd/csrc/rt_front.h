@@ -523,20 +523,14 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
 enum : uint32_t { TS_IDLE = 0, TS_ENTER = 1, TS_TRAV = 2 };
 
 // ALL_LDS: every model's occupancy bitmap fits the LDS budget (the host checks)
-template <bool STATS, bool ALL_LDS>
+// HAS_LONG: some cell of some model has more than 32 entries (the box screen exists only in that instantiation)
+template <bool STATS, bool ALL_LDS, bool HAS_LONG = false>
 __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmDevScene S, FrontArgs A, unsigned long long* __restrict__ out_cnt) {
     extern __shared__ uint32_t occ_lds[];  // [A.occ_words]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    {  // stage the occupancy bitmaps (models back to back; those that do not fit stay in HBM)
-        uint32_t base = 0;
-        for (uint32_t m = 0; m < S.n_models; ++m) {
-            const uint32_t n = S.models[m].n;
-            const uint32_t words = 7u * ((n * n * n + 31u) >> 5);  // seven bitmaps per model: one per arrival direction
-            if (base + words > A.occ_words) break;
-            const gptr<uint32_t> src = as_global(S.models[m].occupancy7);
-            for (uint32_t i = tid; i < words; i += kBlock) occ_lds[base + i] = src[i];
-            base += words;
-        }
+    {  // stage the seven scene-wide bitmaps (the host passes occ_words = all of them, or 0 when they do not fit)
+        const gptr<uint32_t> src = as_global(S.g_occ7);
+        for (uint32_t i = tid; i < A.occ_words; i += kBlock) occ_lds[i] = src[i];
     }
     __syncthreads();
     Counters cnt;
@@ -560,6 +554,14 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     const gptr<uint32_t> IU = as_global(A.itU);
 
     uint32_t st = TS_IDLE, model_i = 0, q = 0, sgn = 0;
+    uint32_t mw = 0;  // the model the ray is in: cells per side (10 bits) | first scene cell / 32
+    const gptr<RtmDevModel> models_g = (gptr<RtmDevModel>)S.models;
+    const gptr<uint32_t> cell_info = as_global(S.g_cell_info);
+    const gptr<double> cell_rec = as_global(S.g_cell_rec);
+    const gptr<double> cell_frame = as_global(S.g_cell_frame);
+    const gptr<uint32_t> cell_box8 = as_global(S.g_cell_box8);
+    const gptr<uint32_t> occ_glb = as_global(S.g_occ7);
+    const uint32_t occ_dir_words = S.g_occ_dir_words;  // words of one direction's bitmap
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     int ix = 0, iy = 0, iz = 0;
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
@@ -572,7 +574,8 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         F_HAVE = 1u,   // a triangle of the current cell was accepted (core.rs:140-149)
         F_FRESH = 2u,  // the entry cell has not been visited yet: no DDA step before it
         F_OPEN = 4u,   // the current cell's list is not exhausted
-        F_WINIT = 8u   // the window of a newly opened cell has not been set up yet
+        F_WINIT = 8u,  // the window of a newly opened cell has not been set up yet
+        F_LONG = 16u   // the window belongs to a long cell and has not been screened against the entries' boxes yet
     };
     uint32_t fl = 0;
     double bt = 0.0;  // closest model hit of this ray so far, over the models visited (core.rs:79-83)
@@ -580,6 +583,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     bool exhausted = sq >= A.nq;
     uint64_t dg_steps = 0, dg_step_lanes = 0, dg_walks = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_refills = 0, dg_refill_lanes = 0;  // STATS only, wave-uniform
 
+    uint64_t dg_idle = 0, dg_other = 0, dg_wait_t = 0, dg_wait_w = 0;  // STATS: lanes idle / in another state or model at a step; testers waiting in walk steps, walkers in test steps
     uint32_t dg_ray_its = 0, dg_max_walks = 0, dg_max_tests = 0;  // STATS: walk iterations (low half) and test steps of this lane's ray; the lane's maxima
     auto finish_ray = [&]() __attribute__((always_inline)) {
         if (STATS) { dg_max_walks = max(dg_max_walks, dg_ray_its & 0xFFFFu); dg_max_tests = max(dg_max_tests, dg_ray_its >> 16); }
@@ -588,10 +592,15 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         A.res[at64(3, (int)(q & 3u), q >> 2)] = r;
         st = TS_IDLE;
     };
-    auto model_result = [&](const bool hit, const uint32_t m, const uint32_t mobj) __attribute__((always_inline)) {
-        if (hit && !(m_t <= kEps) && (bm == kNoId || m_t < bt || (m_t == bt && mobj < bobj))) {
-            bt = m_t; bm = m; btri = m_tri; bobj = mobj;
+    auto model_result = [&]() __attribute__((always_inline)) {  // the lane's model reports a hit (core.rs:75-83 over the models)
+        const uint32_t mobj = models_g[model_i].obj;
+        if (!(m_t <= kEps) && (bm == kNoId || m_t < bt || (m_t == bt && mobj < bobj))) {
+            bt = m_t; bm = model_i; btri = m_tri; bobj = mobj;
         }
+    };
+    auto leave_model = [&]() __attribute__((always_inline)) {  // on to the next model, or the ray is done
+        model_i += 1u;
+        if (model_i >= S.n_models) finish_ray(); else st = TS_ENTER;
     };
 #define RTF_DDA_ADVANCE()                                                      \
     do {                                                                       \
@@ -651,9 +660,10 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const uint32_t cw = IU[at64(IU_COUNT, IU_CELL, it)];
                     ix = (int)(cw & 1023u) - 1; iy = (int)((cw >> 10) & 1023u) - 1; iz = (int)((cw >> 20) & 1023u) - 1;
                     q = IU[at64(IU_COUNT, IU_Q, it)];
-                    const uint32_t mw = IU[at64(IU_COUNT, IU_M, it)];
-                    model_i = mw & 0xFFFFu;
-                    sgn = mw;
+                    const uint32_t iw = IU[at64(IU_COUNT, IU_M, it)];
+                    model_i = iw & 0xFFFFu;
+                    sgn = iw;
+                    mw = models_g[model_i].n | ((models_g[model_i].cell_base >> 5) << 10);
                     fl = F_FRESH; arr = 6u;
                     bm = kNoId; btri = kNoId; bobj = kNoId; bt = 0.0;
                     if (STATS) dg_ray_its = 0;
@@ -698,6 +708,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         tdy = ((double)sy * M.cell[1]) / d.y;
                         tdz = ((double)sz * M.cell[2]) / d.z;
                         sgn = (sx > 0 ? IM_SX : 0u) | (sy > 0 ? IM_SY : 0u) | (sz > 0 ? IM_SZ : 0u);
+                        mw = M.n | ((M.cell_base >> 5) << 10);
                         fl = F_FRESH; arr = 6u;
                         st = TS_TRAV;
                     }
@@ -705,60 +716,45 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             }
             if (st == TS_ENTER) finish_ray();  // no model left
         }
-        const unsigned long long traversing = __ballot(st == TS_TRAV);
-        if (!traversing) continue;
-        // ---- traversal: lanes in the same model as the first traversing lane step together (mm is wave-uniform)
-        const int first_t = __ffsll((long long)traversing) - 1;
-        const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)model_i, first_t);
-        uint32_t occ_base = 0;  // LDS word offset of this model's bitmap, or 0xFFFFFFFF when it stayed in HBM
-        for (uint32_t j = 0; j <= mm; ++j) {
-            const uint32_t nj = S.models[j].n;
-            const uint32_t words = 7u * ((nj * nj * nj + 31u) >> 5);
-            if (occ_base + words > A.occ_words) { occ_base = 0xFFFFFFFFu; break; }
-            if (j < mm) occ_base += words;
-        }
-        const RtmDevModel& M = S.models[mm];
-        // (wave-uniform by construction; said explicitly so that they live in SGPRs and cost no waits in the loop)
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.n), M_obj = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.obj);
-        const gptr<uint32_t> cell_info = as_global(M.cell_info);
-        const gptr<double> cell_rec = as_global(M.cell_rec);
-        const gptr<uint32_t> occ_glb = as_global(M.occupancy7);
-        const uint32_t occ_dir_words = (n * n * n + 31u) >> 5;  // words of one direction's bitmap
-        const bool occ_in_lds = occ_base != 0xFFFFFFFFu;
-        const bool last_model = mm + 1u >= S.n_models;
+        if (!__ballot(st == TS_TRAV)) continue;
+        // ---- traversal: all traversing lanes step together, whichever model each is in (what differs is `mw`)
         for (;;) {
             // A traversing lane is either WALKING (one DDA step and one bitmap probe per cell) or TESTING (its
             // cell's list is open); each iteration runs one of the two activities, whichever has the lanes.
-            bool mine = st == TS_TRAV && model_i == mm;
+            bool mine = st == TS_TRAV;
             if (mine && (fl & (F_OPEN | F_HAVE)) == F_HAVE) {  // core.rs:147-149: the first cell with any accepted hit ends the walk
                 if (STATS) cnt.v[C_MHIT]++;
-                model_result(true, mm, M_obj);
-                model_i = mm + 1;
-                if (last_model) finish_ray(); else st = TS_ENTER;
+                model_result();
+                leave_model();
                 mine = false;
             }
+            const uint32_t n = mw & 1023u;
             const uint32_t nW = (uint32_t)__popcll(__ballot(mine && !(fl & F_OPEN)));
             const uint32_t nT = (uint32_t)__popcll(__ballot(mine && (fl & F_OPEN)));
             if (nW + nT == 0u) break;
+            if (STATS) {  // what the lanes that do not take part in this step are doing
+                dg_idle += (uint64_t)__popcll(__ballot(st == TS_IDLE));
+                dg_other += (uint64_t)__popcll(__ballot(st != TS_IDLE && !mine));
+            }
             if (nT == 0u || (nW != 0u && nT * 64u < A.t_test_frac * (nW + nT))) {
-                if (STATS) { dg_walks++; dg_walk_lanes += nW; dg_t0 = __builtin_amdgcn_s_memtime(); }
+                if (STATS) { dg_walks++; dg_walk_lanes += nW; dg_wait_t += nT; dg_t0 = __builtin_amdgcn_s_memtime(); }
                 if (STATS && mine && !(fl & F_OPEN)) dg_ray_its++;
 #pragma unroll
                 for (int u = 0; u < RTM_FWALK_UNROLL; ++u) {
-                    if (st == TS_TRAV && model_i == mm && !(fl & F_OPEN)) {
+                    if (st == TS_TRAV && !(fl & F_OPEN)) {
                         if (!(fl & F_FRESH)) RTF_DDA_ADVANCE();  // core.rs:151-167
                         fl &= ~F_FRESH;
                         if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {  // core.rs:129-134
                             if (STATS) cnt.v[C_CELLS]++;
                             // (coordinates and n are below 2^10: 24-bit multiplies are full rate, 32-bit ones a quarter)
-                            const uint32_t cell = __umul24(__umul24((uint32_t)iz, n) + (uint32_t)iy, n) + (uint32_t)ix;
+                            const uint32_t cell = ((mw >> 10) << 5) + __umul24(__umul24((uint32_t)iz, n) + (uint32_t)iy, n) + (uint32_t)ix;
                             uint32_t word;
                             // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one
                             // block, the wait before the bit test would also wait for the previous step's cell_start loads)
                             // the bitmap of the arrival direction: cells whose entries were all tested one step ago count as
                             // empty (the counting build uses the plain occupancy, like the reference)
                             const uint32_t wi = (A.cull ? arr : 6u) * occ_dir_words + (cell >> 5);
-                            if (ALL_LDS || occ_in_lds) word = occ_lds[occ_base + wi];
+                            if (ALL_LDS) word = occ_lds[wi];
                             else word = occ_glb[wi];
                             if ((word >> (cell & 31u)) & 1u) {  // non-empty
                                 // The cell's record is read by the next test phase, not here: a load into registers that
@@ -768,26 +764,75 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                                 fl |= F_WINIT | F_OPEN;
                             }
                         } else {  // left the grid without a hit
-                            model_i = mm + 1;
-                            if (last_model) finish_ray(); else st = TS_ENTER;
+                            leave_model();
                         }
                     }
                 }
                 if (STATS) dg_tw += __builtin_amdgcn_s_memtime() - dg_t0;
             } else {
-                if (STATS) { dg_steps++; dg_step_lanes += nT; dg_t0 = __builtin_amdgcn_s_memtime(); }
+                if (STATS) { dg_steps++; dg_step_lanes += nT; dg_wait_w += nW; dg_t0 = __builtin_amdgcn_s_memtime(); }
                 const bool testing = mine && (fl & F_OPEN);
                 if (STATS && testing) dg_ray_its += 1u << 16;
                 if (testing && (fl & F_WINIT)) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
                     // list range [k, k_end), k < k_end, and the arrival mask: one 32-byte record
                     const gptr<uint32_t> ci = cell_info + (size_t)k * 8;
-                    const uint32_t mw = ci[2 + (arr < 6u ? arr : 0u)];
+                    const uint32_t mw = ci[2 + (arr < 6u ? arr : 0u)], w2 = ci[2];
                     k_end = ci[1];
                     k = ci[0];
                     const uint32_t len = k_end - k;
                     const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
                     wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
+                    if (len > 32u) { arr = 8u + w2; fl |= F_LONG; }  // a long cell: its frame index travels in `arr` (rewritten by the next DDA step)
                     fl &= ~F_WINIT;
+                }
+                // Long cells: the window's entries are first tested against their 8-byte boxes (rtm_internal.h cell_box8) and
+                // only the entries whose box the ray's LINE meets keep their bit.  All arithmetic is f32 in the cell's own
+                // frame -- origin at the point of the ray closest to the region's centre (computed in f64), one unit per
+                // quantum -- where coordinates stay below a few hundred, so f32 rounding (1e-4 quantum) is far inside the
+                // one-quantum enlargement of the boxes.  A non-finite ray rejects nothing.
+                if (HAS_LONG && A.cull && __ballot(testing && (fl & F_LONG))) {
+                    const bool scan = testing && (fl & F_LONG) != 0u;
+                    fl &= ~F_LONG;
+                    float olx = 0.f, oly = 0.f, olz = 0.f, ivx = 0.f, ivy = 0.f, ivz = 0.f;
+                    bool finite = false;
+                    if (scan) {
+                        const gptr<double> F = cell_frame + (size_t)(arr - 8u) * 8;
+                        const V3 ctr = ld3(F), iq = ld3(F + 3);
+                        const V3 w = ctr - o;
+                        const double ts = dot(w, d) / dot(d, d);
+                        const V3 pl = (ray_at(o, d, ts) - ctr) * iq;
+                        olx = (float)(pl.x + 127.5); oly = (float)(pl.y + 127.5); olz = (float)(pl.z + 127.5);
+                        const float dlx = (float)(d.x * iq.x), dly = (float)(d.y * iq.y), dlz = (float)(d.z * iq.z);
+                        finite = fabsf(olx) + fabsf(oly) + fabsf(olz) + fabsf(dlx) + fabsf(dly) + fabsf(dlz) < __builtin_inff();
+                        // 1 / direction, kept finite: a (near-)zero component makes its slab [-big, +big] or empty, as it should
+                        ivx = fabsf(dlx) >= 1e-30f ? 1.0f / dlx : __builtin_copysignf(1e30f, dlx);
+                        ivy = fabsf(dly) >= 1e-30f ? 1.0f / dly : __builtin_copysignf(1e30f, dly);
+                        ivz = fabsf(dlz) >= 1e-30f ? 1.0f / dlz : __builtin_copysignf(1e30f, dlz);
+                    }
+                    const uint32_t nwin = scan ? min(k_end - k, 32u) : 0u;
+                    uint32_t pass = 0u;
+                    for (uint32_t j0 = 0; __ballot(j0 < nwin); j0 += 8u) {
+                        uint32_t w0[8], w1[8];
+#pragma unroll
+                        for (uint32_t u = 0; u < 8u; ++u) {
+                            const uint32_t e = k + min(j0 + u, nwin ? nwin - 1u : 0u);
+                            const gptr<uint32_t> bp = cell_box8 + (size_t)e * 2;
+                            w0[u] = scan ? bp[0] : 0u; w1[u] = scan ? bp[1] : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 8u; ++u) {
+                            const float x0 = (float)(w0[u] & 255u), y0 = (float)((w0[u] >> 8) & 255u), z0 = (float)((w0[u] >> 16) & 255u);
+                            const float x1 = (float)(w0[u] >> 24), y1 = (float)(w1[u] & 255u), z1 = (float)((w1[u] >> 8) & 255u);
+                            const float ax = (x0 - olx) * ivx, bx = (x1 - olx) * ivx;
+                            const float ay = (y0 - oly) * ivy, by = (y1 - oly) * ivy;
+                            const float az = (z0 - olz) * ivz, bz = (z1 - olz) * ivz;
+                            const float tlo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+                            const float thi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                            const bool miss = tlo > thi;  // (false when anything is NaN)
+                            pass |= (!miss && j0 + u < nwin) ? (1u << (j0 + u)) : 0u;
+                        }
+                    }
+                    if (scan && finite) wmask &= pass;  // (a window left empty moves on at the end of this step)
                 }
                 if (nT <= 4u && A.coop) {
                     // A few rays are testing (the end of a launch: some long rays are left).  The other lanes test the
@@ -906,28 +951,28 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     fl = (fl & ~F_HAVE) | (have ? F_HAVE : 0u);
                     if (STATS) cnt.v[C_TRI] += cntw;
                 }
-                if (testing && wmask == 0u) {  // window done: the next 32 entries of a long list, or the cell is finished
+                if (testing && wmask == 0u && (fl & F_OPEN)) {  // window done: the next 32 entries of a long list, or the cell is finished
                     if (k_end - k > 32u) {
                         k += 32u;
                         const uint32_t len = k_end - k;
                         wmask = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
+                        fl |= F_LONG;  // (only long cells have a second window: its entries are screened by their boxes first)
                     } else {
                         fl &= ~F_OPEN;
                     }
                 }
                 if (STATS) dg_tt += __builtin_amdgcn_s_memtime() - dg_t0;
             }
-            const unsigned long long still = __ballot(st == TS_TRAV && model_i == mm);
+            const unsigned long long still = __ballot(st == TS_TRAV);
             if (!still) break;
             if (!exhausted && (uint32_t)__popcll(__ballot(st == TS_IDLE)) >= A.refill) break;
             if ((uint32_t)__popcll(still) < A.t_min_lanes && __ballot(st == TS_ENTER)) break;
         }
         // a hit accepted in the last iteration (the loop may leave before its next top)
-        if (st == TS_TRAV && model_i == mm && (fl & (F_OPEN | F_HAVE)) == F_HAVE) {
+        if (st == TS_TRAV && (fl & (F_OPEN | F_HAVE)) == F_HAVE) {
             if (STATS) cnt.v[C_MHIT]++;
-            model_result(true, mm, M_obj);
-            model_i = mm + 1;
-            if (last_model) finish_ray(); else st = TS_ENTER;
+            model_result();
+            leave_model();
         }
     }
 #undef RTF_DDA_ADVANCE
@@ -956,6 +1001,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         const uint64_t dv[8] = {dg_steps, dg_step_lanes, dg_walks, dg_walk_lanes, dg_slots, dg_slot_lanes, dg_refills, dg_refill_lanes};
         for (int i = 0; i < 8; ++i)
             if (dv[i]) atomicAdd(out_cnt + 9 + i, (unsigned long long)dv[i]);
+        const uint64_t dw[4] = {dg_idle, dg_other, dg_wait_t, dg_wait_w};
+        for (int i = 0; i < 4; ++i)
+            if (dw[i]) atomicAdd(out_cnt + 28 + i, (unsigned long long)dw[i]);
     }
 }
 

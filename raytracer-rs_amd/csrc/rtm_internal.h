@@ -25,11 +25,8 @@ struct RtmDevModel {
     const double* tri_pos;       // n_tris x 9: v0 xyz, (v1-v0) xyz, (v2-v0) xyz  -- edges of model.rs:46-47 / :20-21
     const double* tri_nrm;       // n_tris x 9
     const uint32_t* occupancy;   // n^3 bits: cell non-empty
-    const uint32_t* occupancy7;  // seven bitmaps back to back: arrival directions -x,+x,-y,+y,-z,+z (bit = the cell has an entry that was
-                                 // not already tested in the neighbour the step came from), then the plain occupancy (entry cell)
-    const uint32_t* cell_info;   // n^3 x 8: list start, list end, then six masks -- which of the (<= 32) entries are NOT also listed in the
-                                 // neighbour cell a DDA step along -x,+x,-y,+y,-z,+z came from (rt_front.h)
-    const double* cell_rec;      // n_tri_idx x 10, in list order: the tri_pos record of entry k, then its triangle index (as integer bits)
+    uint32_t cell_base;          // first cell of this model in the scene-wide arrays of the ray-front path (a multiple of 32)
+    uint32_t reserved;
 };
 
 struct RtmDevScene {
@@ -42,4 +39,15 @@ struct RtmDevScene {
     const RtmDevModel* models;
     const double* lights;     // n_lights x 8: px py pz r g b radius pad
     const double* materials;  // n_materials x 4: r g b type(0.0|1.0)
+    // ---- the ray-front path's grids, over the cells of all models (model m's cell c is scene cell models[m].cell_base + c):
+    const uint32_t* g_cell_info;  // cells x 8: list start, list end (positions in g_cell_rec), then six masks -- which of the (<= 32)
+                                  // entries are NOT also listed in the neighbour cell a DDA step along -x,+x,-y,+y,-z,+z came from;
+                                  // cells with more than 32 entries ("long cells") hold their frame index in word 2 instead
+    const double* g_cell_rec;     // entries x 10, in list order: v0, v1-v0, v2-v0 of the entry's triangle, then its index in the model
+    const uint32_t* g_occ7;       // seven bitmaps of g_occ_dir_words words each: arrival directions -x,+x,-y,+y,-z,+z (bit = the cell has an
+                                  // entry that was not already tested in the neighbour the step came from), then the plain occupancy
+    uint32_t g_occ_dir_words, g_reserved;
+    const double* g_cell_frame;   // long cells x 8: centre xyz of the region that bounds the cell's triangles, quanta per unit length xyz, 2 spare
+    const uint32_t* g_cell_box8;  // entries x 2 (meaningful for entries of long cells): the triangle's bounding box in the region's 8-bit
+                                  // local coordinates, rounded outwards: word 0 = x0 | y0<<8 | z0<<16 | x1<<24, word 1 = y1 | z1<<8
 };
