@@ -531,8 +531,7 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             {
                 std::vector<double>& frames = g_frames;
                 const size_t frames_before = frames.size();
-                g_box8.resize((size_t)(entry_base + M.n_tri_idx) * 2, 0u);
-                uint32_t* const box8 = g_box8.data() + (size_t)entry_base * 2;
+                std::vector<uint32_t>& box8 = g_box8;  // the boxes of the long cells only, each cell's from a 16-byte boundary
                 for (size_t c = 0; c < n3; ++c) {
                     const uint32_t b = start[c], e = start[c + 1];
                     if (e - b <= 32u) continue;
@@ -560,7 +559,14 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
                     const uint32_t frame = (uint32_t)(frames.size() / 8);
                     for (int a = 0; a < 3; ++a) frames.push_back(ctr[a]);
                     for (int a = 0; a < 3; ++a) frames.push_back(iq[a]);
-                    frames.push_back(0.0); frames.push_back(0.0);
+                    {   // slot 6: (first box of this cell) - (global list position of its first entry), modulo 2^32, as raw bits
+                        if (box8.size() % 4u) box8.resize(box8.size() + 2, 0u);
+                        const uint64_t bits = (uint32_t)(box8.size() / 2 - (entry_base + b));
+                        double as_double;
+                        std::memcpy(&as_double, &bits, 8);
+                        frames.push_back(as_double);
+                        frames.push_back(0.0);
+                    }
                     info[c * 8 + 2] = frame;
                     for (uint32_t k = b; k < e; ++k) {
                         double lo[3], hi[3];
@@ -572,8 +578,8 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
                             q0[a] = (usable && l >= 1.0 && l <= 255.0) ? (uint32_t)std::floor(l) - 1u : 0u;
                             q1[a] = (usable && h >= 0.0 && h <= 254.0) ? (uint32_t)std::ceil(h) + 1u : 255u;
                         }
-                        box8[(size_t)k * 2] = q0[0] | (q0[1] << 8) | (q0[2] << 16) | (q1[0] << 24);
-                        box8[(size_t)k * 2 + 1] = q1[1] | (q1[2] << 8);
+                        box8.push_back(q0[0] | (q0[1] << 8) | (q0[2] << 16) | (q1[0] << 24));
+                        box8.push_back(q1[1] | (q1[2] << 8));
                     }
                 }
                 sd->n_long_cells += (frames.size() - frames_before) / 8;
@@ -608,7 +614,7 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
         }
         V.g_occ_dir_words = (uint32_t)W;
         sd->occ7_words = (uint32_t)std::min<size_t>(W * 7, 0xFFFFFFFFu);
-        g_box8.resize(g_box8.size() + 8, 0u);
+        g_box8.resize(((g_box8.size() + 3) & ~(size_t)3) + 8, 0u);
         if ((rc = upload(sd, occ7_all, &V.g_occ7)) || (rc = upload(sd, g_info, &V.g_cell_info)) || (rc = upload(sd, g_rec, &V.g_cell_rec)) ||
             (rc = upload(sd, g_frames, &V.g_cell_frame)) || (rc = upload(sd, g_box8, &V.g_cell_box8)))
             return fail(rc);
@@ -637,7 +643,9 @@ bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
 // words of the seven scene-wide bitmaps when they fit the trace kernel's LDS budget (all of them or none: a probe that
 // may go either way would wait for both memories)
 uint32_t front_occ_words(const rtm_scene_dev* sd) {
-    return sd->occ7_words <= (uint32_t)rtw::kOccLdsWordsMax ? sd->occ7_words : 0u;
+    if (sd->occ7_words <= (uint32_t)rtw::kOccLdsWordsMax) return sd->occ7_words;
+    if (sd->occ7_words / 7u <= (uint32_t)rtw::kOccLdsWordsMax) return sd->occ7_words / 7u;  // the plain occupancy alone
+    return 0u;
 }
 
 // One frame as bands of rows; per band: round 0 (camera rays), then shade/trace rounds until no path is alive.
@@ -766,7 +774,8 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t shade_wgs = nq / 4u;
     // (a small chunk's launches are latency-bound: three workgroups per CU leave room for the other chunk's waves; measured)
     const uint32_t trace_wgs = (uint32_t)g_num_cus * (g_front_trace_wgs_env ? g_front_trace_wgs_per_cu : (np_max >= ((size_t)8 << 20) ? (uint32_t)RTM_FRONT_OCC : 3u));
-    const bool all_lds = occ_words == sd->occ7_words;  // the bitmaps are staged in LDS
+    const bool all_lds = occ_words != 0u || sd->occ7_words == 0u;  // the bitmaps the walk probes are staged in LDS
+    const bool occ_plain_only = all_lds && occ_words != sd->occ7_words;
     uint32_t chunk = 0;
     for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk, ++chunk) {
         const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
@@ -781,6 +790,8 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
         A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
         A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
         A.occ_words = occ_words;
+        A.occ_dirs = occ_plain_only ? 0u : 1u;
+        A.occ_src_off = occ_plain_only ? 6u * (sd->occ7_words / 7u) : 0u;
         A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
         A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);
         A.itD = (double*)(B + o_itD); A.itU = (uint32_t*)(B + o_itU);

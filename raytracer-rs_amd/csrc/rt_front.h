@@ -38,6 +38,7 @@ using namespace rtd;
 #endif
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multiplied by 10 in 32 bits
+constexpr int kModelTab = 256;               // models whose grid word the trace kernel keeps in LDS
 constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 10 bits each, biased by one
 
 // Per-path state, array of structures of arrays: paths in blocks of 64, a block's fields back to back, so double
@@ -92,7 +93,9 @@ struct FrontArgs {
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
     uint32_t coop;              // trace kernel: 1 = when at most four rays of a wave are testing, the other lanes test their entries
     uint32_t t_test_frac, t_min_lanes;
-    uint32_t occ_words;
+    uint32_t occ_words;         // bitmap words the trace kernel stages in LDS, starting at word occ_src_off of g_occ7
+    uint32_t occ_src_off;
+    uint32_t occ_dirs;          // 1: the walk probes the bitmap of its arrival direction; 0: only the plain occupancy is used (and staged)
     double* D[2];               // path state, streamed from one buffer to the other every round
     uint32_t* U[2];
     double* fin;                // [at64(3, c, home slot)]: colour of a finished sample
@@ -527,9 +530,12 @@ enum : uint32_t { TS_IDLE = 0, TS_ENTER = 1, TS_TRAV = 2 };
 template <bool STATS, bool ALL_LDS, bool HAS_LONG = false>
 __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmDevScene S, FrontArgs A, unsigned long long* __restrict__ out_cnt) {
     extern __shared__ uint32_t occ_lds[];  // [A.occ_words]
+    __shared__ uint32_t mtab[kModelTab];     // per model: cells per side | first scene cell / 32 << 10 (what a lane keeps in `mw`)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t m = tid; m < min(S.n_models, (uint32_t)kModelTab); m += kBlock)
+        mtab[m] = S.models[m].n | ((S.models[m].cell_base >> 5) << 10);
     {  // stage the seven scene-wide bitmaps (the host passes occ_words = all of them, or 0 when they do not fit)
-        const gptr<uint32_t> src = as_global(S.g_occ7);
+        const gptr<uint32_t> src = as_global(S.g_occ7) + A.occ_src_off;
         for (uint32_t i = tid; i < A.occ_words; i += kBlock) occ_lds[i] = src[i];
     }
     __syncthreads();
@@ -567,6 +573,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
     uint32_t k = 0, k_end = 0, m_tri = 0;  // [k, k_end): the rest of the current cell's list, k = first entry of the 32-entry window
     uint32_t wmask = 0, arr = 6;           // untested entries of the window; the direction the ray arrived from
+    uint32_t wmask_hi = 0;                 // long cells: the 32 entries behind the window, already screened (F_HI)
     double m_t = 0.0;
     // per-ray flags, kept as bits of one VGPR: as separate bools they live in SGPR lane masks and every join of the
     // divergent control flow below costs a handful of scalar mask merges per flag (half of the kernel's instructions)
@@ -575,11 +582,12 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         F_FRESH = 2u,  // the entry cell has not been visited yet: no DDA step before it
         F_OPEN = 4u,   // the current cell's list is not exhausted
         F_WINIT = 8u,  // the window of a newly opened cell has not been set up yet
-        F_LONG = 16u   // the window belongs to a long cell and has not been screened against the entries' boxes yet
+        F_LONG = 16u,  // the window belongs to a long cell and has not been screened against the entries' boxes yet
+        F_HI = 32u     // the box screen also covered the 32 entries after the window: their mask waits in wmask_hi
     };
     uint32_t fl = 0;
     double bt = 0.0;  // closest model hit of this ray so far, over the models visited (core.rs:79-83)
-    uint32_t bm = kNoId, btri = kNoId, bobj = kNoId;
+    uint32_t bm = kNoId, btri = kNoId;
     bool exhausted = sq >= A.nq;
     uint64_t dg_steps = 0, dg_step_lanes = 0, dg_walks = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_refills = 0, dg_refill_lanes = 0;  // STATS only, wave-uniform
 
@@ -593,9 +601,11 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         st = TS_IDLE;
     };
     auto model_result = [&]() __attribute__((always_inline)) {  // the lane's model reports a hit (core.rs:75-83 over the models)
-        const uint32_t mobj = models_g[model_i].obj;
-        if (!(m_t <= kEps) && (bm == kNoId || m_t < bt || (m_t == bt && mobj < bobj))) {
-            bt = m_t; bm = model_i; btri = m_tri; bobj = mobj;
+        if (!(m_t <= kEps)) {
+            bool take = bm == kNoId || m_t < bt;
+            // equal t in two models: the object earlier in the scene file keeps it (core.rs:79) -- looked up only then
+            if (!take && m_t == bt) take = models_g[model_i].obj < models_g[bm].obj;
+            if (take) { bt = m_t; bm = model_i; btri = m_tri; }
         }
     };
     auto leave_model = [&]() __attribute__((always_inline)) {  // on to the next model, or the ray is done
@@ -616,6 +626,34 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         tmz = az_ ? nz_ : tmz;                                                 \
         arr = ax_ ? ((sgn & IM_SX) ? 1u : 0u) : (ay_ ? ((sgn & IM_SY) ? 3u : 2u) : ((sgn & IM_SZ) ? 5u : 4u)); \
     } while (0)
+
+    // One step of the walk for the calling lanes: DDA advance (core.rs:151-167), bounds (core.rs:129-134), bitmap probe.
+    auto walk_step = [&]() __attribute__((always_inline)) {
+        const uint32_t n = mw & 1023u;
+        if (!(fl & F_FRESH)) RTF_DDA_ADVANCE();
+        fl &= ~F_FRESH;
+        if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {
+            if (STATS) cnt.v[C_CELLS]++;
+            // (coordinates and n are below 2^10: 24-bit multiplies are full rate, 32-bit ones a quarter)
+            const uint32_t cell = ((mw >> 10) << 5) + __umul24(__umul24((uint32_t)iz, n) + (uint32_t)iy, n) + (uint32_t)ix;
+            uint32_t word;
+            // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one block, the wait
+            // before the bit test would also wait for outstanding global loads.)  The bitmap of the arrival direction:
+            // cells whose entries were all tested one step ago count as empty; the counting build, and scenes whose seven
+            // bitmaps do not fit in LDS together (occ_dirs = 0: only the plain one is staged), use the plain occupancy.
+            const uint32_t wi = (A.occ_dirs ? (A.cull ? arr : 6u) : 0u) * occ_dir_words + (cell >> 5);
+            if (ALL_LDS) word = occ_lds[wi];
+            else word = occ_glb[wi];
+            if ((word >> (cell & 31u)) & 1u) {  // non-empty
+                // The cell's record is read by the next test phase, not here: a load into registers that an earlier
+                // step's load may still be filling makes the compiler wait for all of them.
+                k = cell;
+                fl |= F_WINIT | F_OPEN;
+            }
+        } else {  // left the grid without a hit
+            leave_model();
+        }
+    };
 
     for (;;) {
         unsigned long long idle = __ballot(st == TS_IDLE);
@@ -663,9 +701,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const uint32_t iw = IU[at64(IU_COUNT, IU_M, it)];
                     model_i = iw & 0xFFFFu;
                     sgn = iw;
-                    mw = models_g[model_i].n | ((models_g[model_i].cell_base >> 5) << 10);
+                    mw = model_i < (uint32_t)kModelTab ? mtab[model_i] : (models_g[model_i].n | ((models_g[model_i].cell_base >> 5) << 10));
                     fl = F_FRESH; arr = 6u;
-                    bm = kNoId; btri = kNoId; bobj = kNoId; bt = 0.0;
+                    bm = kNoId; btri = kNoId; bt = 0.0;
                     if (STATS) dg_ray_its = 0;
                     st = TS_TRAV;
                 }
@@ -728,7 +766,6 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 leave_model();
                 mine = false;
             }
-            const uint32_t n = mw & 1023u;
             const uint32_t nW = (uint32_t)__popcll(__ballot(mine && !(fl & F_OPEN)));
             const uint32_t nT = (uint32_t)__popcll(__ballot(mine && (fl & F_OPEN)));
             if (nW + nT == 0u) break;
@@ -741,32 +778,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 if (STATS && mine && !(fl & F_OPEN)) dg_ray_its++;
 #pragma unroll
                 for (int u = 0; u < RTM_FWALK_UNROLL; ++u) {
-                    if (st == TS_TRAV && !(fl & F_OPEN)) {
-                        if (!(fl & F_FRESH)) RTF_DDA_ADVANCE();  // core.rs:151-167
-                        fl &= ~F_FRESH;
-                        if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {  // core.rs:129-134
-                            if (STATS) cnt.v[C_CELLS]++;
-                            // (coordinates and n are below 2^10: 24-bit multiplies are full rate, 32-bit ones a quarter)
-                            const uint32_t cell = ((mw >> 10) << 5) + __umul24(__umul24((uint32_t)iz, n) + (uint32_t)iy, n) + (uint32_t)ix;
-                            uint32_t word;
-                            // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one
-                            // block, the wait before the bit test would also wait for the previous step's cell_start loads)
-                            // the bitmap of the arrival direction: cells whose entries were all tested one step ago count as
-                            // empty (the counting build uses the plain occupancy, like the reference)
-                            const uint32_t wi = (A.cull ? arr : 6u) * occ_dir_words + (cell >> 5);
-                            if (ALL_LDS) word = occ_lds[wi];
-                            else word = occ_glb[wi];
-                            if ((word >> (cell & 31u)) & 1u) {  // non-empty
-                                // The cell's record is read by the next test phase, not here: a load into registers that
-                                // an earlier step's load may still be filling makes the compiler wait for all of them,
-                                // one memory latency in every walk iteration that opens a cell.
-                                k = cell;
-                                fl |= F_WINIT | F_OPEN;
-                            }
-                        } else {  // left the grid without a hit
-                            leave_model();
-                        }
-                    }
+                    if (st == TS_TRAV && !(fl & F_OPEN)) walk_step();
                 }
                 if (STATS) dg_tw += __builtin_amdgcn_s_memtime() - dg_t0;
             } else {
@@ -782,6 +794,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const uint32_t len = k_end - k;
                     const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
                     wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
+                    fl &= ~F_HI;
                     if (len > 32u) { arr = 8u + w2; fl |= F_LONG; }  // a long cell: its frame index travels in `arr` (rewritten by the next DDA step)
                     fl &= ~F_WINIT;
                 }
@@ -794,45 +807,65 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const bool scan = testing && (fl & F_LONG) != 0u;
                     fl &= ~F_LONG;
                     float olx = 0.f, oly = 0.f, olz = 0.f, ivx = 0.f, ivy = 0.f, ivz = 0.f;
+                    uint32_t boff = 0u;
                     bool finite = false;
                     if (scan) {
                         const gptr<double> F = cell_frame + (size_t)(arr - 8u) * 8;
                         const V3 ctr = ld3(F), iq = ld3(F + 3);
+                        boff = (uint32_t)__double_as_longlong(F[6]);  // where the cell's boxes are, relative to its list positions
                         const V3 w = ctr - o;
-                        const double ts = dot(w, d) / dot(d, d);
+                        // (any point of the ray near the region will do as the frame's origin: an approximate quotient)
+                        const double ts = dot(w, d) * (double)__builtin_amdgcn_rcpf((float)dot(d, d));
                         const V3 pl = (ray_at(o, d, ts) - ctr) * iq;
                         olx = (float)(pl.x + 127.5); oly = (float)(pl.y + 127.5); olz = (float)(pl.z + 127.5);
                         const float dlx = (float)(d.x * iq.x), dly = (float)(d.y * iq.y), dlz = (float)(d.z * iq.z);
-                        finite = fabsf(olx) + fabsf(oly) + fabsf(olz) + fabsf(dlx) + fabsf(dly) + fabsf(dlz) < __builtin_inff();
+                        // (the screen is used only where f32 is good for 1e-2 quantum: frame origin within 2^16 quanta of the region)
+                        finite = fabsf(olx) + fabsf(oly) + fabsf(olz) < 65536.0f && fabsf(dlx) + fabsf(dly) + fabsf(dlz) < __builtin_inff();
                         // 1 / direction, kept finite: a (near-)zero component makes its slab [-big, +big] or empty, as it should
                         ivx = fabsf(dlx) >= 1e-30f ? 1.0f / dlx : __builtin_copysignf(1e30f, dlx);
                         ivy = fabsf(dly) >= 1e-30f ? 1.0f / dly : __builtin_copysignf(1e30f, dly);
                         ivz = fabsf(dlz) >= 1e-30f ? 1.0f / dlz : __builtin_copysignf(1e30f, dlz);
                     }
-                    const uint32_t nwin = scan ? min(k_end - k, 32u) : 0u;
-                    uint32_t pass = 0u;
-                    for (uint32_t j0 = 0; __ballot(j0 < nwin); j0 += 8u) {
-                        uint32_t w0[8], w1[8];
+                    const float cx = -olx * ivx, cy = -oly * ivy, cz = -olz * ivz;
+                    const uint32_t nwin = scan ? min(k_end - k, 64u) : 0u;  // the window and the 32 entries after it
+                    // the cell's boxes are packed from a 16-byte boundary (two entries per load); lanes that do not scan read entry 0
+                    const uint32_t bbase = scan ? k + boff : 0u;
+                    uint32_t pass_h[2] = {0u, 0u};
+                    typedef float v2f __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    const __attribute__((address_space(1))) u4* const box4 = (const __attribute__((address_space(1))) u4*)cell_box8;
 #pragma unroll
-                        for (uint32_t u = 0; u < 8u; ++u) {
-                            const uint32_t e = k + min(j0 + u, nwin ? nwin - 1u : 0u);
-                            const gptr<uint32_t> bp = cell_box8 + (size_t)e * 2;
-                            w0[u] = scan ? bp[0] : 0u; w1[u] = scan ? bp[1] : 0u;
-                        }
+                    for (uint32_t half = 0; half < 2u; ++half) {
+                        uint32_t pass = 0u;
+                        for (uint32_t j0 = half * 32u; j0 < half * 32u + 32u && __ballot(j0 < nwin); j0 += 8u) {
+                            u4 bx[4];
 #pragma unroll
-                        for (uint32_t u = 0; u < 8u; ++u) {
-                            const float x0 = (float)(w0[u] & 255u), y0 = (float)((w0[u] >> 8) & 255u), z0 = (float)((w0[u] >> 16) & 255u);
-                            const float x1 = (float)(w0[u] >> 24), y1 = (float)(w1[u] & 255u), z1 = (float)((w1[u] >> 8) & 255u);
-                            const float ax = (x0 - olx) * ivx, bx = (x1 - olx) * ivx;
-                            const float ay = (y0 - oly) * ivy, by = (y1 - oly) * ivy;
-                            const float az = (z0 - olz) * ivz, bz = (z1 - olz) * ivz;
-                            const float tlo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-                            const float thi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-                            const bool miss = tlo > thi;  // (false when anything is NaN)
-                            pass |= (!miss && j0 + u < nwin) ? (1u << (j0 + u)) : 0u;
+                            for (uint32_t u = 0; u < 4u; ++u)  // (entries beyond the list read the list's last pair; their bits are dropped below)
+                                bx[u] = box4[(bbase + min(j0 + 2u * u, nwin ? (nwin - 1u) & ~1u : 0u)) >> 1];
+#pragma unroll
+                            for (uint32_t u = 0; u < 8u; ++u) {
+                                const uint32_t w0 = (u & 1u) ? bx[u >> 1].z : bx[u >> 1].x, w1 = (u & 1u) ? bx[u >> 1].w : bx[u >> 1].y;
+                                const float x0 = (float)(w0 & 255u), y0 = (float)((w0 >> 8) & 255u), z0 = (float)((w0 >> 16) & 255u);
+                                const float x1 = (float)(w0 >> 24), y1 = (float)(w1 & 255u), z1 = (float)((w1 >> 8) & 255u);
+                                // (x - ol) * iv as one fused multiply-add with c = -ol * iv: its rounding moves a face by 1e-5 quantum
+                                const v2f tx = __builtin_elementwise_fma(v2f{x0, x1}, v2f{ivx, ivx}, v2f{cx, cx});
+                                const v2f ty = __builtin_elementwise_fma(v2f{y0, y1}, v2f{ivy, ivy}, v2f{cy, cy});
+                                const v2f tz = __builtin_elementwise_fma(v2f{z0, z1}, v2f{ivz, ivz}, v2f{cz, cz});
+                                const float tlo = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+                                const float thi = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+                                pass |= (tlo > thi) ? 0u : (1u << ((j0 & 31u) + u));  // (a comparison with NaN is false: the entry stays)
+                            }
                         }
+                        pass_h[half] = pass;
                     }
-                    if (scan && finite) wmask &= pass;  // (a window left empty moves on at the end of this step)
+                    unsigned long long pass = ((unsigned long long)pass_h[1] << 32) | pass_h[0];
+                    pass &= nwin >= 64u ? ~0ull : ((1ull << nwin) - 1ull);
+                    if (scan) {  // (a window left empty moves on at the end of this step)
+                        if (!finite) pass = nwin >= 64u ? ~0ull : ((1ull << nwin) - 1ull);
+                        wmask &= (uint32_t)pass;
+                        wmask_hi = (uint32_t)(pass >> 32);
+                        fl |= F_HI;
+                    }
                 }
                 if (nT <= 4u && A.coop) {
                     // A few rays are testing (the end of a launch: some long rays are left).  The other lanes test the
@@ -952,13 +985,19 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     if (STATS) cnt.v[C_TRI] += cntw;
                 }
                 if (testing && wmask == 0u && (fl & F_OPEN)) {  // window done: the next 32 entries of a long list, or the cell is finished
-                    if (k_end - k > 32u) {
+                    const uint32_t adv = (HAS_LONG && (fl & F_HI)) ? 64u : 32u;  // entries dealt with so far, counted from k
+                    if (HAS_LONG && (fl & F_HI) && wmask_hi != 0u) {  // the second half of what the screen covered
                         k += 32u;
+                        wmask = wmask_hi;
+                        wmask_hi = 0u;
+                        fl &= ~F_HI;
+                    } else if (k_end - k > adv) {
+                        k += adv;
                         const uint32_t len = k_end - k;
                         wmask = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
-                        fl |= F_LONG;  // (only long cells have a second window: its entries are screened by their boxes first)
+                        fl = (fl & ~F_HI) | F_LONG;  // (only long cells have further windows: their entries are screened by their boxes first)
                     } else {
-                        fl &= ~F_OPEN;
+                        fl &= ~(F_OPEN | F_HI);
                     }
                 }
                 if (STATS) dg_tt += __builtin_amdgcn_s_memtime() - dg_t0;

@@ -47,7 +47,9 @@ struct RtmDevScene {
     const uint32_t* g_occ7;       // seven bitmaps of g_occ_dir_words words each: arrival directions -x,+x,-y,+y,-z,+z (bit = the cell has an
                                   // entry that was not already tested in the neighbour the step came from), then the plain occupancy
     uint32_t g_occ_dir_words, g_reserved;
-    const double* g_cell_frame;   // long cells x 8: centre xyz of the region that bounds the cell's triangles, quanta per unit length xyz, 2 spare
-    const uint32_t* g_cell_box8;  // entries x 2 (meaningful for entries of long cells): the triangle's bounding box in the region's 8-bit
-                                  // local coordinates, rounded outwards: word 0 = x0 | y0<<8 | z0<<16 | x1<<24, word 1 = y1 | z1<<8
+    const double* g_cell_frame;   // long cells x 8: centre xyz of the region that bounds the cell's triangles, quanta per unit length xyz,
+                                  // (index of the cell's first box in g_cell_box8) - (list position of its first entry) as integer bits, 1 spare
+    const uint32_t* g_cell_box8;  // two words per entry of a long cell, the cell's entries in list order from a 16-byte boundary: the
+                                  // triangle's bounding box in the region's 8-bit local coordinates, rounded outwards:
+                                  // word 0 = x0 | y0<<8 | z0<<16 | x1<<24, word 1 = y1 | z1<<8
 };

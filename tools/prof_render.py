@@ -9,7 +9,11 @@ rtm.init(0)
 name = sys.argv[1] if len(sys.argv) > 1 else "bunny"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-s = rtm.Scene(path=os.path.join(ROOT, "assets", "scene", name + ".scene"), base_dir=os.path.join(ROOT, "assets"))
+if name == "soup":
+    import bench
+    s = bench.soup_scene(rtm, 1_000_000, 20250725)
+else:
+    s = rtm.Scene(path=os.path.join(ROOT, "assets", "scene", name + ".scene"), base_dir=os.path.join(ROOT, "assets"))
 p = rtm.make_params(s.width, s.height, spp=spp, seed=0)
 buf = torch.empty(s.height * s.width * 3, dtype=torch.float64, device="cuda")
 for _ in range(iters):

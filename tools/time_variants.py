@@ -8,7 +8,11 @@ import torch
 from rtm_loader import load_package
 R = load_package(); R.init(0)
 name, spp = sys.argv[1], int(sys.argv[2])
-s = R.Scene(path=os.path.join(%r, "assets/scene", name + ".scene"), base_dir=os.path.join(%r, "assets"))
+if name == "soup":
+    import bench
+    s = bench.soup_scene(R, 1_000_000, 20250725)
+else:
+    s = R.Scene(path=os.path.join(%r, "assets/scene", name + ".scene"), base_dir=os.path.join(%r, "assets"))
 p = R.make_params(s.width, s.height, spp=spp, seed=0)
 buf = torch.empty(s.height * s.width * 3, dtype=torch.float64, device="cuda")
 s.time_render_device(p, buf.data_ptr(), 1)
