@@ -43,22 +43,30 @@ def algorithmic_flops(c: dict) -> float:
             9.0 * c["cells_visited"] + 41.0 * c["tri_tests"] + 66.0 * c["model_hits"])
 
 
-def soup_scene(rtm, n_tris: int, seed: int):
+SOUP_TEXT = ("size 3840 3840\n\ncamera from (4.0, -8, 0) to (0, 0, 7)\n\nplane (0, 0, 1.0) 10 white\n"
+             "plane (0, 1.0, 0) 2 metal:white\n"
+             'model "./models/teapot.obj" white > scale 0.4 > translate (2.5, 1.2, 6)\n'
+             "light (1, 0, 2) green\nlight (-1, 0, 2) blue")
+
+
+def soup_arrays(n_tris: int, seed: int):
     """BASELINE config 5's synthetic soup: N triangles, centres U([-2,2]^3)+(0,0,7), edge vectors U([-s,s]^3)
-    with s = 0.02, geometric normals, numpy Philox(seed); two planes and two lights as in the bunny scene."""
+    with s = 0.02, geometric normals, numpy Philox(seed).  Returns (pos9, nrm9) as float32 [N, 9]."""
     import numpy as np
-    txt = ("size 3840 3840\n\ncamera from (4.0, -8, 0) to (0, 0, 7)\n\nplane (0, 0, 1.0) 10 white\n"
-           "plane (0, 1.0, 0) 2 metal:white\n"
-           'model "./models/teapot.obj" white > scale 0.4 > translate (2.5, 1.2, 6)\n'
-           "light (1, 0, 2) green\nlight (-1, 0, 2) blue")
-    # teapot.obj has no `vn` lines: the reference loader would refuse it; geometric normals are synthesised (stated)
-    s = rtm.Scene(text=txt, base_dir=ASSETS, synth_normals=True)
     rng = np.random.Generator(np.random.Philox(seed))
     c = rng.uniform(-2, 2, (n_tris, 1, 3)) + np.array([0.0, 0.0, 7.0])
     pos = (c + rng.uniform(-0.02, 0.02, (n_tris, 3, 3))).astype(np.float32)
     g = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0])
     g /= np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
-    s.add_triangles(pos.reshape(n_tris, 9), np.repeat(g, 3, axis=0).reshape(n_tris, 9).astype(np.float32))
+    return pos.reshape(n_tris, 9), np.repeat(g, 3, axis=0).reshape(n_tris, 9).astype(np.float32)
+
+
+def soup_scene(rtm, n_tris: int, seed: int):
+    """Config 5's scene on the library's front end: SOUP_TEXT (two planes and two lights as in the bunny scene, the
+    teapot) plus the soup as a second model."""
+    # teapot.obj has no `vn` lines: the reference loader would refuse it; geometric normals are synthesised (stated)
+    s = rtm.Scene(text=SOUP_TEXT, base_dir=ASSETS, synth_normals=True)
+    s.add_triangles(*soup_arrays(n_tris, seed))
     return s
 
 
