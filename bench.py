@@ -70,25 +70,36 @@ def soup_scene(rtm, n_tris: int, seed: int):
     return s
 
 
-def cpu_baseline(workload: str, width: int, height: int, target_s: float = 15.0):
-    """The oracle (kind "port": C++ restatement of the rayon path, faithful-cost mode) on this box's host cores,
-    on a bounded sample of the same workload: the full frame at a reduced spp."""
+def cpu_baseline(workload: str, width: int, height: int, soup_tris: int, target_s: float = 15.0):
+    """The oracle (kind "port": C++ restatement of the rayon path, faithful-cost mode) on ALL of this box's host cores
+    (rayon's default, main.rs:158), on a bounded sample of the same workload: the full frame at a reduced spp (named
+    scenes) or a reduced frame at 1 spp (config 5, whose 3840^2 frame costs minutes per sample on a CPU)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle  # CPU baseline leg only
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)  # (the GPU box pins its share in OMP_NUM_THREADS)
     cores = max(1, min(cores, os.cpu_count() or 1))
-    sc = oracle.OracleScene(path=os.path.join(ASSETS, "scene", workload + ".scene"), base_dir=ASSETS)
+    if workload == "soup":
+        sc = oracle.OracleScene(text=SOUP_TEXT, base_dir=ASSETS, allow_missing_normals=True)
+        sc.add_triangles(*soup_arrays(soup_tris, 20250725))
+        width = height = 512
+    else:
+        sc = oracle.OracleScene(path=os.path.join(ASSETS, "scene", workload + ".scene"), base_dir=ASSETS)
     t0 = time.perf_counter()
     sc.render(spp=1, seed=0, width=width, height=height, faithful=True, n_threads=cores, counters=False)
     t1 = time.perf_counter() - t0
-    spp = int(max(1, min(20, target_s / max(t1, 1e-3))))
+    if workload == "soup":  # grow the frame, keep 1 spp
+        side = int(min(3840, 512 * max(1.0, (target_s / max(t1, 1e-3)) ** 0.5))) // 8 * 8
+        width = height = side
+        spp = 1
+    else:
+        spp = int(max(1, min(20, target_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
     sc.render(spp=spp, seed=0, width=width, height=height, faithful=True, n_threads=cores, counters=False)
     dt = time.perf_counter() - t0
     cnt = sc.render(spp=spp, seed=0, width=width, height=height, faithful=False, n_threads=cores)["counters"]
     rays = cnt["rays_camera"] + cnt["rays_bounce"] + cnt["rays_shadow"]
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{workload} {width}x{height} at {spp} spp (of 20), all pixels, faithful-cost mode "
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"{workload} {width}x{height} at {spp} spp, all pixels, faithful-cost mode "
                       f"(per-access Mat4::apply, model.rs:108-122), {dt:.1f} s"}
 
 
@@ -158,6 +169,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def progress(what):  # (stderr: a long run must be seen to be alive; stdout carries the one JSON line)
+        if rank == 0:
+            print(f"[bench] {what}", file=sys.stderr, flush=True)
+
+    progress(f"{args.workload} {W}x{H} at {args.spp} spp: counting frame")
     # exact ray / work counts of the whole frame (outside the timed region)
     cnt = scene.render_device(p_local, local.data_ptr(), stats=True, stream=stream.cuda_stream)
     if world > 1:
@@ -166,6 +182,7 @@ def main():
         cnt = dict(zip(rtm.STAT_NAMES, (int(v) for v in t.tolist())))
     rays = cnt["rays_camera"] + cnt["rays_bounce"] + cnt["rays_shadow"]
 
+    progress(f"{args.warmup} warm-up + {args.steps} timed steps")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -174,6 +191,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    progress(f"{dt / args.steps * 1e3:.2f} ms per step; timing the dominant kernel")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -186,19 +204,40 @@ def main():
         step()
     barrier()
     ev_ms, ev_n = rtm.timed_events_collect()
+    # ... once more with ONE chunk of the frame in flight at a time: no other kernel runs beside the one being timed, so
+    # these durations add up to less than the frame (the default, two chunks on two internal streams, overlaps the late
+    # rounds of one chunk with the heavy rounds of the other: faster frames, but each launch is stretched by its neighbour)
+    progress("... and with one chunk of the frame in flight at a time")
+    rtm.set_tuning("front_streams", 1)
+    iso_steps = max(1, min(args.steps, 5))
+    step()
+    barrier()
+    rtm.timed_events_collect()
+    t0 = time.perf_counter()
+    for _ in range(iso_steps):
+        step()
+    barrier()
+    iso_frame_ms = (time.perf_counter() - t0) / iso_steps * 1e3
+    iso_ms, iso_n = rtm.timed_events_collect()
     rtm.set_tuning("front_timed_events", 0)
-    # ... and the per-kernel split of one frame plus the counters of the work that kernel really did
+    # ... and the per-kernel split of one frame (still one chunk at a time) plus the counters of the work really done
+    progress("per-kernel split and work counters")
     prof = scene.profile_render_device(p_local, local.data_ptr(), stream=stream.cuda_stream)
-    frame_ms = scene.time_render_device(p_local, local.data_ptr(), max(3, min(args.steps, 10)), stream=stream.cuda_stream)
+    rtm.set_tuning("front_streams", 2)
+    frame_ms = scene.time_render_device(p_local, local.data_ptr(), max(1, min(args.steps, 10)), stream=stream.cuda_stream)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = rays * args.steps / dt / 1e6
         # SURVEY 8(d) per-unit figures x the units the trace kernel processed: 48 B ray + 40 B result per traced ray,
         # 8 B per cell visited, 76 B per triangle test
-        n_launch = max(1, prof["trace_launches"])
-        abytes = (88.0 * prof["traced_rays"] + 8.0 * prof["cells_visited"] + 76.0 * prof["tri_tests"]) / n_launch
+        # (per launch in the regime of the timed frames: two chunks in flight make twice as many launches of half the size)
+        n_launch = max(1, ev_n // args.steps if ev_n else prof["trace_launches"])
+        n_launch_iso = max(1, iso_n // iso_steps if iso_n else prof["trace_launches"])
+        frame_bytes = 88.0 * prof["traced_rays"] + 8.0 * prof["cells_visited"] + 76.0 * prof["tri_tests"]
+        abytes = frame_bytes / n_launch
         kern_ms = ev_ms / ev_n if ev_n else prof["trace_ms"] / n_launch  # (single-kernel formulations record no events)
+        kern_ms_iso = iso_ms / iso_n if iso_n else kern_ms
         achieved = abytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -206,33 +245,45 @@ def main():
             traffic = json.load(open(tpath)).get(f"{args.workload}_{W}x{H}_{args.spp}spp_n{world}", {}).get("hbm_bytes_per_launch")
         flops = (9.0 * prof["cells_visited"] + 41.0 * prof["tri_tests"]) / n_launch
         single = prof["shade_launches"] == 0
+        headline = args.workload == "bunny" and W == 1200 and args.spp == 20
         out = {
-            "metric": "Mrays/s (primary+shadow) bunny 1200^2 20spp" if args.workload == "bunny" and W == 1200 and args.spp == 20
+            "metric": "Mrays/s (primary+shadow) bunny 1200^2 20spp" if headline
             else f"Mrays/s (primary+shadow) {args.workload} {W}x{H} {args.spp}spp",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "reference scene files (assets/), counter-based RNG seed 0" if args.workload != "soup"
-            else f"synthetic {args.soup_tris}-triangle soup, numpy Philox seed 20250725",
+            else f"synthetic {args.soup_tris}-triangle soup (numpy Philox seed 20250725) + teapot.obj with synthesised normals",
             "config": {"workload": f"{args.workload} {W}x{H} at {args.spp} spp, 10 bounces, grid 32^3",
                        "rays_per_frame": rays, "rays_camera": cnt["rays_camera"], "rays_bounce": cnt["rays_bounce"],
                        "rays_shadow": cnt["rays_shadow"], "samples_per_s": W * H * args.spp * args.steps / dt,
-                       "rays_note": "rays the reference casts for this frame (exact counters, pinned to the oracle's). The device path "
-                                    "answers shadow rays whose light is behind the surface (main.rs:96 fails) without tracing them, and "
-                                    f"only rays that enter a model's box reach the trace kernel ({prof['traced_rays']} on this rank)",
+                       "rays_issued": prof["rays_total"], "rays_traced": prof["traced_rays"],
+                       "mrays_issued_per_s": prof["rays_total"] * world / (ms_per_step * 1e-3) / 1e6 if world == 1 else None,
+                       "rays_note": "value counts the rays the REFERENCE casts for this frame (rays_per_frame: exact counters, pinned to "
+                                    "the oracle's). The device path answers shadow rays whose light is behind the surface (main.rs:96 "
+                                    "fails) without tracing them: rays_issued is what it does issue, and of those only the rays that "
+                                    "enter a model's box reach the trace kernel: rays_traced (both on this rank)",
                        "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>" if single else "rtf::front_trace_kernel<false, true>",
-                         "kernel_ms": kern_ms, "kernel_launches_timed": ev_n, "launches_per_frame": n_launch, "algorithmic_bytes_per_launch": abytes,
-                         "note": "scene and queues are L2/MALL-resident per round: the kernel is bound by the vector-memory "
-                                 "pipeline (per-lane gathers of 80 B triangle records) and FP64 VALU issue, see valu and DESIGN.md"},
+                         "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>" if single else
+                         ("rtf::front_trace_kernel<false, true, true>" if args.workload == "soup" else "rtf::front_trace_kernel<false, true, false>"),
+                         "bytes_are": "algorithmic (SURVEY 8d: 88 B per traced ray + 8 B per cell + 76 B per triangle test), not measured; "
+                                      "`traffic` is the measured HBM figure",
+                         "kernel_ms": kern_ms, "kernel_launches_timed": ev_n, "launches_per_frame": n_launch,
+                         "kernel_ms_isolated": kern_ms_iso, "isolated_launches_timed": iso_n, "isolated_frame_ms": iso_frame_ms,
+                         "frac_isolated": frame_bytes / n_launch_iso / (kern_ms_iso * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "launches_per_frame_isolated": n_launch_iso,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "binding_limit": "VALU issue (f64 triangle tests, f32 box screen) and vector-memory latency of per-lane gathers: "
+                                          "the scene and the queues of a round are L2/MALL-resident, see valu and DESIGN.md"},
             "valu": {"achieved_tflops": flops / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
                      "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "algorithmic_flops_per_launch": flops},
-            "pipeline": {"frame_ms": frame_ms, "shade_ms": prof["shade_ms"], "trace_ms": prof["trace_ms"], "resolve_ms": prof["resolve_ms"],
-                         "shade_launches": prof["shade_launches"], "trace_launches": prof["trace_launches"],
+            "pipeline": {"frame_ms": frame_ms, "one_chunk_at_a_time": True, "shade_ms": prof["shade_ms"], "trace_ms": prof["trace_ms"],
+                         "resolve_ms": prof["resolve_ms"], "shade_launches": prof["shade_launches"], "trace_launches": prof["trace_launches"],
                          "traced_rays": prof["traced_rays"], "cells_visited": prof["cells_visited"], "tri_tests": prof["tri_tests"]},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload != "soup":
-            out["cpu_baseline"] = cpu_baseline(args.workload, W, H)
+        if world == 1 and not args.no_cpu_baseline:
+            progress("CPU baseline (oracle, all host cores)")
+            out["cpu_baseline"] = cpu_baseline(args.workload, W, H, args.soup_tris)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -938,8 +938,8 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     };
     if (out_stats) {
         unsigned long long* d_cnt = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_cnt, 32 * sizeof(unsigned long long)));
-        hipError_t e = hipMemsetAsync(d_cnt, 0, 32 * sizeof(unsigned long long), stream);
+        HIP_TRY(hipMalloc((void**)&d_cnt, 40 * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_cnt, 0, 40 * sizeof(unsigned long long), stream);
         if (e == hipSuccess) e = launch(true, d_cnt);
         unsigned long long h[32] = {0};
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, stream);
@@ -1091,7 +1091,7 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
         unsigned long long h[40] = {0};
         if (rc == RTM_OK) e = hipMemcpyAsync(h, d_buf, sizeof h, hipMemcpyDeviceToHost, stream);
         if (rc == RTM_OK && e == hipSuccess) e = hipStreamSynchronize(stream);
-        out->rays_total = h[0] + h[1] + h[2];
+        out->rays_total = h[0] + h[1] + h[2] - h[33];  // (h[33]: shadow queries answered without a ray)
         out->cells_visited = h[6];
         out->tri_tests = h[7];
         out->traced_rays = h[32];

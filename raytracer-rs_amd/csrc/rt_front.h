@@ -163,6 +163,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
     Counters cnt;
     if (STATS)
         for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
+    uint64_t n_culled = 0;  // STATS: shadow queries answered without a ray (their light is behind the surface)
 
     for (uint32_t k = 0; k * 64u < n_in_list; ++k) {  // wave-uniform trip count
         const uint32_t idx = k * 64u + lane;
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     const bool lit = eff > 0.001;  // main.rs:96: otherwise the query's answer is never used
                     if (lit) fl |= FB_C1 << j;
                     trace = lit || !A.cull;
+                    if (STATS && !trace) n_culled++;
                 }
                 issue(1u + j, go && trace, dir);  // (the host turns culling off when exact work counters are wanted)
             };
@@ -519,6 +521,10 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         my_ctr[CT_CLAIM] = 0u;
     }
     flush_counters<STATS>(cnt, out_cnt);
+    if (STATS) {
+        const uint64_t v = wave_sum(n_culled);
+        if (lane == 0 && v) atomicAdd(out_cnt + 33, (unsigned long long)v);
+    }
 }
 
 // ================================================================================================
