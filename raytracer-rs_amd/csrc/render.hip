@@ -776,90 +776,106 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t trace_wgs = (uint32_t)g_num_cus * (g_front_trace_wgs_env ? g_front_trace_wgs_per_cu : (np_max >= ((size_t)8 << 20) ? (uint32_t)RTM_FRONT_OCC : 3u));
     const bool all_lds = occ_words != 0u || sd->occ7_words == 0u;  // the bitmaps the walk probes are staged in LDS
     const bool occ_plain_only = all_lds && occ_words != sd->occ7_words;
-    uint32_t chunk = 0;
-    for (uint32_t band0 = 0; band0 < bands_total; band0 += bands_per_chunk, ++chunk) {
-        const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
-        hipStream_t stream = lanes[chunk % n_conc];                            // (shadows the caller's stream inside the loop)
-        char* const B = ws_base + (size_t)(chunk % n_conc) * ws_one;
-        rtf::FrontArgs A{};
-        A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_bounces = p->max_bounces; A.seed = p->seed;
-        A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
-        A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
-        A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
-        A.cull = (stats && !(prof && prof->keep_cull) && !std::getenv("RTM_DIAG_KEEP_CULL")) ? 0u : g_front_cull;
-        A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
-        A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
-        A.occ_words = occ_words;
-        A.occ_dirs = occ_plain_only ? 0u : 1u;
-        A.occ_src_off = occ_plain_only ? 6u * (sd->occ7_words / 7u) : 0u;
-        A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
-        A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);
-        A.itD = (double*)(B + o_itD); A.itU = (uint32_t*)(B + o_itU);
-        A.nq = nq; A.cap_l = ((((A.np + 63u) / 64u) + nq - 1) / nq) * 64u; A.cap_i = A.cap_l * 3u; A.cap_items = nq * A.cap_i;
-        A.ctr = (uint32_t*)(B + o_ctr);
-        const uint32_t shade_wgs0 = shade_wgs;
+    // The chunks run n_conc at a time, each on its own stream and work-space slot, and their launches are ENQUEUED round by
+    // round across the group: queued chunk after chunk, the second stream's first kernel reached the GPU only after the
+    // host had queued all ~24 launches of the first chunk (0.9 ms into a 6.5 ms frame share).
+    const uint32_t shade_wgs0 = shade_wgs;
+    const uint32_t n_chunks = (bands_total + bands_per_chunk - 1) / bands_per_chunk;
+    for (uint32_t chunk0 = 0; chunk0 < n_chunks; chunk0 += n_conc) {
+        const uint32_t n_group = std::min(n_conc, n_chunks - chunk0);
+        rtf::FrontArgs args_of[kFrontStreamsMax];
+        for (uint32_t gi = 0; gi < n_group; ++gi) {
+            const uint32_t chunk = chunk0 + gi, band0 = chunk * bands_per_chunk;
+            const uint32_t nb = std::min(bands_per_chunk, bands_total - band0);
+            char* const B = ws_base + (size_t)(chunk % n_conc) * ws_one;
+            rtf::FrontArgs A{};
+            A.W = p->width; A.H = p->height; A.spp = p->spp; A.max_bounces = p->max_bounces; A.seed = p->seed;
+            A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
+            A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
+            A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
+            A.cull = (stats && !(prof && prof->keep_cull) && !std::getenv("RTM_DIAG_KEEP_CULL")) ? 0u : g_front_cull;
+            A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
+            A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
+            A.occ_words = occ_words;
+            A.occ_dirs = occ_plain_only ? 0u : 1u;
+            A.occ_src_off = occ_plain_only ? 6u * (sd->occ7_words / 7u) : 0u;
+            A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
+            A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);
+            A.itD = (double*)(B + o_itD); A.itU = (uint32_t*)(B + o_itU);
+            A.nq = nq; A.cap_l = ((((A.np + 63u) / 64u) + nq - 1) / nq) * 64u; A.cap_i = A.cap_l * 3u; A.cap_items = nq * A.cap_i;
+            A.ctr = (uint32_t*)(B + o_ctr);
+            args_of[gi] = A;
+        }
         for (uint32_t r = 0; r < rounds; ++r) {
-            mark(0, false, stream);
-            if (r == 0) {
-                if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
-                else hipLaunchKernelGGL((rtf::front_shade_kernel<false, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
-            } else {
-                if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
-                else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
-            }
-            mark(0, true, stream);
-            if (prof && prof->d_items && !prof->keep_cull)
-                hipLaunchKernelGGL(front_sum_items_kernel, dim3(32), dim3(256), 0, stream, A.ctr, nq, prof->d_items);
-            if (r + 1 < rounds) {  // the last round only finalises
-                mark(1, false, stream);
-                const size_t lds = (size_t)occ_words * 4;
-                const int variant = (stats ? 4 : 0) | (all_lds ? 2 : 0) | (sd->n_long_cells ? 1 : 0);
-                switch (variant) {
+            for (uint32_t gi = 0; gi < n_group; ++gi) {
+                const rtf::FrontArgs& A = args_of[gi];
+                hipStream_t stream = lanes[(chunk0 + gi) % n_conc];  // (shadows the caller's stream inside the loop)
+                mark(0, false, stream);
+                if (r == 0) {
+                    if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+                    else hipLaunchKernelGGL((rtf::front_shade_kernel<false, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+                } else {
+                    if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+                    else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+                }
+                mark(0, true, stream);
+                if (prof && prof->d_items && !prof->keep_cull)
+                    hipLaunchKernelGGL(front_sum_items_kernel, dim3(32), dim3(256), 0, stream, A.ctr, nq, prof->d_items);
+                if (r + 1 < rounds) {  // the last round only finalises
+                    mark(1, false, stream);
+                    const size_t lds = (size_t)occ_words * 4;
+                    const int variant = (stats ? 4 : 0) | (all_lds ? 2 : 0) | (sd->n_long_cells ? 1 : 0);
+                    switch (variant) {
 #define RTM_TRACE_CASE(v, S_, L_, G_) \
     case v: hipLaunchKernelGGL((rtf::front_trace_kernel<S_, L_, G_>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt); break;
-                    RTM_TRACE_CASE(0, false, false, false) RTM_TRACE_CASE(1, false, false, true)
-                    RTM_TRACE_CASE(2, false, true, false) RTM_TRACE_CASE(3, false, true, true)
-                    RTM_TRACE_CASE(4, true, false, false) RTM_TRACE_CASE(5, true, false, true)
-                    RTM_TRACE_CASE(6, true, true, false) RTM_TRACE_CASE(7, true, true, true)
+                        RTM_TRACE_CASE(0, false, false, false) RTM_TRACE_CASE(1, false, false, true)
+                        RTM_TRACE_CASE(2, false, true, false) RTM_TRACE_CASE(3, false, true, true)
+                        RTM_TRACE_CASE(4, true, false, false) RTM_TRACE_CASE(5, true, false, true)
+                        RTM_TRACE_CASE(6, true, true, false) RTM_TRACE_CASE(7, true, true, true)
 #undef RTM_TRACE_CASE
+                    }
+                    mark(1, true, stream);
                 }
-                mark(1, true, stream);
-            }
-            HIP_TRY(hipGetLastError());
-            if (g_front_debug_rounds && !fixed) {  // RTM_FRONT_DEBUG_ROUNDS=1: list lengths after every round (synchronises; diagnostics only)
-                std::vector<uint32_t> h((size_t)nq * rtf::CT_STRIDE);
-                HIP_TRY(hipStreamSynchronize(stream));
-                HIP_TRY(hipMemcpy(h.data(), A.ctr, h.size() * 4, hipMemcpyDeviceToHost));
-                uint64_t live = 0, items = 0;
-                uint32_t live_max = 0, items_max = 0;
-                for (uint32_t j = 0; j < nq; ++j) {
-                    const uint32_t l = h[(size_t)j * rtf::CT_STRIDE + ((r + 1u) & 1u)], it = h[(size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS];
-                    live += l; items += it;
-                    live_max = std::max(live_max, l); items_max = std::max(items_max, it);
-                }
-                std::fprintf(stderr, "[rtm front] round %u: live %llu (max %u per sub-list of %u), items %llu (max %u)\n", r,
-                             (unsigned long long)live, live_max, nq, (unsigned long long)items, items_max);
-                if (stats) {  // trace diagnostics of this round (the counters are cumulative; the maximum is reset here)
-                    static unsigned long long prev[32];
-                    unsigned long long h2[32];
-                    HIP_TRY(hipMemcpy(h2, d_cnt, sizeof h2, hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemset(d_cnt + 21, 0, 8));
-                    HIP_TRY(hipMemset(d_cnt + 26, 0, 16));
-                    if (r == 0) std::memset(prev, 0, sizeof prev);
-                    auto dl = [&](int i) { return (double)(h2[i] - prev[i]); };
-                    std::fprintf(stderr, "[rtm front]   trace: slowest wave %llu ticks with %llu iterations (most walk iterations of a ray %llu, most test steps %llu), mean wave %.0f ticks; walk iters %.0f (%.1f lanes) test steps %.0f (%.1f lanes); of wave time: refill %.1f%% walk %.1f%% test %.1f%%\n",
-                                 h2[21] >> 24, h2[21] & 0xFFFFFFull, h2[26], h2[27], dl(22) > 0 ? dl(20) / dl(22) : 0.0, dl(11), dl(11) > 0 ? dl(12) / dl(11) : 0.0, dl(9),
-                                 dl(9) > 0 ? dl(10) / dl(9) : 0.0, 100.0 * dl(23) / dl(20), 100.0 * dl(24) / dl(20), 100.0 * dl(25) / dl(20));
-                    std::memcpy(prev, h2, sizeof prev);
-                    prev[21] = 0;
-                    prev[26] = 0; prev[27] = 0;
+                HIP_TRY(hipGetLastError());
+                if (g_front_debug_rounds && !fixed) {  // RTM_FRONT_DEBUG_ROUNDS=1: list lengths after every round (synchronises; diagnostics only)
+                    std::vector<uint32_t> h((size_t)nq * rtf::CT_STRIDE);
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    HIP_TRY(hipMemcpy(h.data(), A.ctr, h.size() * 4, hipMemcpyDeviceToHost));
+                    uint64_t live = 0, items = 0;
+                    uint32_t live_max = 0, items_max = 0;
+                    for (uint32_t j = 0; j < nq; ++j) {
+                        const uint32_t l = h[(size_t)j * rtf::CT_STRIDE + ((r + 1u) & 1u)], it = h[(size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS];
+                        live += l; items += it;
+                        live_max = std::max(live_max, l); items_max = std::max(items_max, it);
+                    }
+                    std::fprintf(stderr, "[rtm front] round %u: live %llu (max %u per sub-list of %u), items %llu (max %u)\n", r,
+                                 (unsigned long long)live, live_max, nq, (unsigned long long)items, items_max);
+                    if (stats) {  // trace diagnostics of this round (the counters are cumulative; the maximum is reset here)
+                        static unsigned long long prev[32];
+                        unsigned long long h2[32];
+                        HIP_TRY(hipMemcpy(h2, d_cnt, sizeof h2, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemset(d_cnt + 21, 0, 8));
+                        HIP_TRY(hipMemset(d_cnt + 26, 0, 16));
+                        if (r == 0) std::memset(prev, 0, sizeof prev);
+                        auto dl = [&](int i) { return (double)(h2[i] - prev[i]); };
+                        std::fprintf(stderr, "[rtm front]   trace: slowest wave %llu ticks with %llu iterations (most walk iterations of a ray %llu, most test steps %llu), mean wave %.0f ticks; walk iters %.0f (%.1f lanes) test steps %.0f (%.1f lanes); of wave time: refill %.1f%% walk %.1f%% test %.1f%%\n",
+                                     h2[21] >> 24, h2[21] & 0xFFFFFFull, h2[26], h2[27], dl(22) > 0 ? dl(20) / dl(22) : 0.0, dl(11), dl(11) > 0 ? dl(12) / dl(11) : 0.0, dl(9),
+                                     dl(9) > 0 ? dl(10) / dl(9) : 0.0, 100.0 * dl(23) / dl(20), 100.0 * dl(24) / dl(20), 100.0 * dl(25) / dl(20));
+                        std::memcpy(prev, h2, sizeof prev);
+                        prev[21] = 0;
+                        prev[26] = 0; prev[27] = 0;
+                    }
                 }
             }
         }
-        mark(2, false, stream);
-        hipLaunchKernelGGL(rtf::front_resolve_kernel, dim3((A.npix + 255) / 256), block, 0, stream, A, d_rgb);
-        mark(2, true, stream);
-        HIP_TRY(hipGetLastError());
+        for (uint32_t gi = 0; gi < n_group; ++gi) {
+            const rtf::FrontArgs& A = args_of[gi];
+            hipStream_t stream = lanes[(chunk0 + gi) % n_conc];
+            mark(2, false, stream);
+            hipLaunchKernelGGL(rtf::front_resolve_kernel, dim3((A.npix + 255) / 256), block, 0, stream, A, d_rgb);
+            mark(2, true, stream);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (n_conc > 1) {  // join: the caller's stream continues after every internal stream
         for (uint32_t i = 0; i < n_conc; ++i) {
@@ -1073,6 +1089,17 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
     prof.d_items = d_buf + 32;
     int rc = render_front(sd, p, n_rows, occ_words, d_rgb, nullptr, nullptr, nullptr, stream, &prof);
     hipError_t e = hipStreamSynchronize(stream);
+    if (std::getenv("RTM_PROFILE_ROUNDS") && rc == RTM_OK && e == hipSuccess) {  // per-launch durations, in launch order
+        for (int k = 0; k < 2; ++k) {
+            std::fprintf(stderr, "[rtm profile] %s launches (ms):", k ? "trace" : "shade");
+            for (auto& pr : prof.ev[k]) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+                std::fprintf(stderr, " %.3f", ms);
+            }
+            std::fprintf(stderr, "\n");
+        }
+    }
     double* const slot[3] = {&out->shade_ms, &out->trace_ms, &out->resolve_ms};
     for (int k = 0; k < 3; ++k)
         for (auto& pr : prof.ev[k]) {
