@@ -811,12 +811,19 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 const rtf::FrontArgs& A = args_of[gi];
                 hipStream_t stream = lanes[(chunk0 + gi) % n_conc];  // (shadows the caller's stream inside the loop)
                 mark(0, false, stream);
-                if (r == 0) {
-                    if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
-                    else hipLaunchKernelGGL((rtf::front_shade_kernel<false, true>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
-                } else {
-                    if (stats) hipLaunchKernelGGL((rtf::front_shade_kernel<true, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
-                    else hipLaunchKernelGGL((rtf::front_shade_kernel<false, false>), dim3(shade_wgs0), block, 0, stream, sd->view, A, r, d_obj, d_tri, d_cnt);
+                {
+                    const bool tabs = sd->view.n_lights <= (uint32_t)rtf::kShadeLights && sd->view.n_materials <= (uint32_t)rtf::kShadeMats &&
+                                      sd->view.n_models <= (uint32_t)rtf::kShadeModels;
+                    const size_t slds = tabs ? rtf::kShadeLdsBytes : 0;
+                    switch ((stats ? 4 : 0) | (r == 0 ? 2 : 0) | (tabs ? 1 : 0)) {
+#define RTM_SHADE_CASE(v, S_, R_, T_) \
+    case v: hipLaunchKernelGGL((rtf::front_shade_kernel<S_, R_, T_>), dim3(shade_wgs0), block, slds, stream, sd->view, A, r, d_obj, d_tri, d_cnt); break;
+                        RTM_SHADE_CASE(0, false, false, false) RTM_SHADE_CASE(1, false, false, true)
+                        RTM_SHADE_CASE(2, false, true, false) RTM_SHADE_CASE(3, false, true, true)
+                        RTM_SHADE_CASE(4, true, false, false) RTM_SHADE_CASE(5, true, false, true)
+                        RTM_SHADE_CASE(6, true, true, false) RTM_SHADE_CASE(7, true, true, true)
+#undef RTM_SHADE_CASE
+                    }
                 }
                 mark(0, true, stream);
                 if (prof && prof->d_items && !prof->keep_cull)

@@ -38,6 +38,8 @@ using namespace rtd;
 #endif
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multiplied by 10 in 32 bits
+constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256;  // table sizes the shade kernel keeps in LDS
+constexpr size_t kShadeLdsBytes = (size_t)(kShadeLights * 8 + kShadeMats * 4) * 8 + (size_t)kShadeModels * 2 * 4;
 constexpr int kModelTab = 256;               // models whose grid word the trace kernel keeps in LDS
 constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 10 bits each, biased by one
 
@@ -131,10 +133,27 @@ RTM_DEV void flush_counters(const Counters& cnt, unsigned long long* out_cnt) {
 
 // ================================================================================================
 // shade: round 0 creates the camera rays (main.rs:160-168); later rounds consume and re-issue
-template <bool STATS, bool ROUND0>
+// TABS: the light, material and per-model (object, material) tables are staged in LDS (scenes within kShade* entries):
+// the paths of a wave are at different lights and materials, so these are per-lane lookups -- of tables that every wave
+// reads all the time.
+template <bool STATS, bool ROUND0, bool TABS>
 __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
                                                               uint32_t* __restrict__ out_tri, unsigned long long* __restrict__ out_cnt) {
     const uint32_t lane = threadIdx.x & 63u;
+    extern __shared__ double sh_tab[];  // [kShadeLights * 8] lights, [kShadeMats * 4] materials, then [kShadeModels * 2] u32 (object, material)
+    if (TABS) {
+        uint32_t* const sh_mod = (uint32_t*)(sh_tab + kShadeLights * 8 + kShadeMats * 4);
+        for (uint32_t i = threadIdx.x; i < S.n_lights * 8u; i += kBlock) sh_tab[i] = S.lights[i];
+        for (uint32_t i = threadIdx.x; i < S.n_materials * 4u; i += kBlock) sh_tab[kShadeLights * 8 + i] = S.materials[i];
+        for (uint32_t i = threadIdx.x; i < S.n_models; i += kBlock) { sh_mod[i * 2] = S.models[i].obj; sh_mod[i * 2 + 1] = S.models[i].mat; }
+        __syncthreads();
+    }
+    const uint32_t* const sh_mod = (const uint32_t*)(sh_tab + kShadeLights * 8 + kShadeMats * 4);
+    auto light_at = [&](uint32_t i, int c) -> double { return TABS ? sh_tab[i * 8u + c] : S.lights[(size_t)i * 8 + c]; };
+    auto light3 = [&](uint32_t i, int c) -> V3 { return mk(light_at(i, c), light_at(i, c + 1), light_at(i, c + 2)); };
+    auto mat_at = [&](uint32_t i, int c) -> double { return TABS ? sh_tab[kShadeLights * 8 + i * 4u + c] : S.materials[(size_t)i * 4 + c]; };
+    auto model_obj = [&](uint32_t m) -> uint32_t { return TABS ? sh_mod[m * 2u] : S.models[m].obj; };
+    auto model_mat = [&](uint32_t m) -> uint32_t { return TABS ? sh_mod[m * 2u + 1u] : S.models[m].mat; };
     // The analytic primitives and the model headers are read by every query of every path, at wave-uniform addresses,
     // and nothing writes them during a frame: through the constant address space they come as scalar loads (one
     // s_load_dwordx8 per sphere) instead of one vector load per lane with its latency in every loop iteration.
@@ -250,19 +269,19 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     if ((fl & FB_TQ0) && r0.model != kNoId) {
                         const uint32_t m = r0.model;
                         const double t = r0.t;
-                        const uint32_t mobj = S.models[m].obj;
+                        const uint32_t mobj = model_obj(m);
                         if (!(t <= kEps) && (t < best0 || (found0 && t == best0 && mobj < h_obj))) {
                             best0 = t; found0 = true;
-                            h_obj = mobj; h_mat = S.models[m].mat; h_kp = (2u << 30) | m; h_tri = r0.tri;
+                            h_obj = mobj; h_mat = model_mat(m); h_kp = (2u << 30) | m; h_tri = r0.tri;
                         }
                     }
                 }
                 const bool b_hit = b_take && found0, b_miss = b_take && !found0;
                 const bool end_sample = a_end || b_miss;
                 const uint32_t mat_old = a_fin ? mat : 0u;
-                const bool metal_old = S.materials[(size_t)mat_old * 4 + 3] != 0.0;
+                const bool metal_old = mat_at(mat_old, 3) != 0.0;
                 const uint32_t mat_new = b_hit ? h_mat : mat_old;
-                const bool metal_new = S.materials[(size_t)mat_new * 4 + 3] != 0.0;
+                const bool metal_new = mat_at(mat_new, 3) != 0.0;
                 const uint32_t bounce_new = bounce + (a_fin ? 1u : 0u);  // index of the vertex a hit creates
                 const bool plastic_hit = b_hit && !metal_new;
                 uint32_t ra[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
@@ -277,8 +296,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     if (li == 0u) diff = mk(0, 0, 0);
                     auto shade = [&](const uint32_t j, const double sba, const uint32_t rm, const double rt) __attribute__((always_inline)) {
                         if (j < n_in && (fl & (FB_C1 << j))) {  // a query that cannot contribute is not looked at
-                            const double* L = S.lights + (size_t)(li + j) * 8;
-                            const V3 lp = ld3(L);
+                            const V3 lp = light3(li + j, 0);
                             const V3 dir = normalize(lp - o);
                             const double dl2 = sqdist(o, lp);
                             double best = sba;
@@ -288,9 +306,10 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                             if (found) occluded = sqdist(ray_at(o, dir, best), o) <= dl2;
                             if (!occluded) {
                                 const double eff = dot(dir, nn);  // > 0.001, or FB_C would not be set
-                                const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
+                                const double lr = light_at(li + j, 6);
+                                const double dd = fmax(dl2 / (lr * lr), 1.0);
                                 const double decay = 1.0 / dd;
-                                diff = diff + ld3(L + 3) * decay * eff;
+                                diff = diff + light3(li + j, 3) * decay * eff;
                             }
                         }
                     };
@@ -302,8 +321,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 }
                 // ---- 3. end of the light loop: the surface's colour, attenuation (main.rs:107-125)
                 if (a_fin) {
-                    const double* mp = S.materials + (size_t)mat_old * 4;
-                    col = col + ld3(mp) * att * (diff * (metal_old ? 0.2 : 0.9));
+                    col = col + mk(mat_at(mat_old, 0), mat_at(mat_old, 1), mat_at(mat_old, 2)) * att * (diff * (metal_old ? 0.2 : 0.9));
                     att = att * (metal_old ? 0.8 : 0.1);
                     ++bounce;
                     fl &= ~FB_HASV;
@@ -489,8 +507,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 V3 dir = mk(0, 0, 1);
                 bool trace = false;
                 if (go) {
-                    const double* L = S.lights + (size_t)(li + j) * 8;
-                    const V3 lp = ld3(L);
+                    const V3 lp = light3(li + j, 0);
                     dir = normalize(lp - o);
                     const double eff = dot(dir, nn);
                     const bool lit = eff > 0.001;  // main.rs:96: otherwise the query's answer is never used

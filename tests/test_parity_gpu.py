@@ -159,7 +159,13 @@ def test_profile_entry_point(rtm_gpu, rtm_scene):
     ref = s.render(spp=4, seed=3, width=w, height=h, stats=True)
     assert np.array_equal(rgb.cpu().numpy(), ref["rgb"])
     c = ref["counters"]
-    assert pr["rays_total"] == c["rays_camera"] + c["rays_bounce"] + c["rays_shadow"]
+    ref_rays = c["rays_camera"] + c["rays_bounce"] + c["rays_shadow"]
+    assert c["rays_camera"] + c["rays_bounce"] < pr["rays_total"] < ref_rays  # issued: the reference's minus the culled shadow queries
+    rtm_gpu.set_tuning("front_cull", 0)
+    try:
+        assert s.profile_render_device(p, rgb.data_ptr())["rays_total"] == ref_rays
+    finally:
+        rtm_gpu.set_tuning("front_cull", 1)
     assert 0 < pr["traced_rays"] <= c["bbox_tests"]
     assert 0 < pr["tri_tests"] <= c["tri_tests"] and 0 < pr["cells_visited"] <= c["cells_visited"]
     assert pr["trace_launches"] >= 1 and pr["shade_launches"] >= 2
