@@ -238,6 +238,22 @@ const rtm_scene* rtm_frontend_scene(const rtm_frontend* fe);
 int rtm_frontend_size(const rtm_frontend* fe, uint32_t* width, uint32_t* height);
 int rtm_frontend_free(rtm_frontend* fe);
 
+/* ---- Model::create_grid (model.rs:147-201) on the device: bins n_tris triangles (pos[k*3+c][t], as in
+ * rtm_model) into cells_per_side^3 cells of the box (bbox_center, bbox_half) exactly as the reference does -- triangle box
+ * grown with Box3::include (box3D.rs:31-45, which is not the true bounding box), corner cells by saturating casts
+ * (model.rs:159-167), lists in ascending triangle order -- and writes offsets (ModelGrid.offset_array, INCLUSIVE prefix sums,
+ * cells^3 entries) and tri_idx (ModelGrid.triangle_indices).  The number of list entries comes back in *out_n_tri_idx; when
+ * tri_idx_capacity is smaller (or the tri_idx pointer NULL) the offsets are still written and the call returns
+ * RTM_ERR_INVALID: allocate that many and call again.  cells_per_side 1..128 (the reference uses 32, core.rs:62).
+ * rtm_grid_build: host pointers in and out.  rtm_grid_build_device: d_pos[9], d_offsets, d_tri_idx are device pointers
+ * (the array d_pos itself is a host array of nine device pointers); synchronises `stream`. */
+int rtm_grid_build(const double* const pos[9], uint32_t n_tris, const double bbox_center[3], const double bbox_half[3],
+                   uint32_t cells_per_side, uint32_t* out_offsets, uint32_t* out_tri_idx, uint64_t tri_idx_capacity,
+                   uint64_t* out_n_tri_idx);
+int rtm_grid_build_device(const double* const d_pos[9], uint32_t n_tris, const double bbox_center[3], const double bbox_half[3],
+                          uint32_t cells_per_side, uint32_t* d_offsets, uint32_t* d_tri_idx, uint64_t tri_idx_capacity,
+                          uint64_t* out_n_tri_idx, void* stream);
+
 /* ---- The reference's whole program, for machines without a Rust toolchain.
  * rtm_write_bmp: what buffer.save(&args.output) writes for an ImageBuffer<Rgb<u8>> (main.rs:173,190; `image` crate
  * 0.25.1 BMP encoder: 54-byte header, 24 bpp, bottom-up, BGR, rows padded to 4 bytes); rgb8 = height*width*3, row-major,

@@ -114,6 +114,8 @@ _lib.rtm_render_rgb8.argtypes = [_vp, C.POINTER(RtmParams), C.c_int, _vp, C.POIN
 _lib.rtm_write_bmp.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _vp]
 _lib.rtm_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
 _lib.rtm_f64_ops_selftest.argtypes = [C.c_uint64, _vp, _vp, _vp]
+_lib.rtm_grid_build.argtypes = [C.POINTER(_PD), C.c_uint32, _PD, _PD, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]
+_lib.rtm_grid_build_device.argtypes = [C.POINTER(_vp), C.c_uint32, _PD, _PD, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), _vp]
 _lib.rtm_frontend_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(_vp)]
 _lib.rtm_frontend_add_triangles.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, _vp]
 _lib.rtm_frontend_scene.restype = C.POINTER(RtmScene)
@@ -126,7 +128,7 @@ EXPORTED_SYMBOLS = (
     "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_profile_render_device", "rtm_trace_rays", "rtm_tonemap_device",
     "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
     "rtm_frontend_size", "rtm_frontend_free", "rtm_render_rgb8", "rtm_write_bmp", "rtm_cli_main", "rtm_timed_events_collect",
-    "rtm_render_device_noalloc", "rtm_noalloc_scratch_bytes")
+    "rtm_render_device_noalloc", "rtm_noalloc_scratch_bytes", "rtm_grid_build", "rtm_grid_build_device")
 
 
 def raw_lib() -> C.CDLL:
@@ -334,6 +336,28 @@ class Scene:
         nrm = np.zeros((n, 3))
         _check(_lib.rtm_trace_rays(self.device_handle(), n, _ptr(rays6), _ptr(obj), _ptr(tri), _ptr(t), _ptr(nrm)))
         return dict(obj_id=obj, tri_id=tri, t=t, normal=nrm)
+
+
+def grid_build(pos9, bbox_center, bbox_half, cells_per_side: int = 32):
+    """rtm_grid_build: create_grid (model.rs:147-201) on the GPU.  pos9 = [n_tris, 9] f64 (v0 xyz, v1 xyz, v2 xyz).
+    Returns (offsets [cells^3] u32 inclusive prefix sums, tri_idx u32)."""
+    if not _inited:
+        init()
+    pos9 = np.asarray(pos9, dtype=np.float64).reshape(-1, 9)
+    n = pos9.shape[0]
+    cols = [np.ascontiguousarray(pos9[:, a]) for a in range(9)]
+    arr = (_PD * 9)(*[c.ctypes.data_as(_PD) for c in cols])
+    ctr = (C.c_double * 3)(*[float(v) for v in bbox_center])
+    half = (C.c_double * 3)(*[float(v) for v in bbox_half])
+    offsets = np.zeros(cells_per_side ** 3, dtype=np.uint32)
+    need = C.c_uint64()
+    rc = _lib.rtm_grid_build(arr, n, ctr, half, cells_per_side, _ptr(offsets), None, 0, C.byref(need))
+    if rc != 0 and not (rc == -1 and need.value > 0):
+        _check(rc)
+    tri_idx = np.zeros(need.value, dtype=np.uint32)
+    if need.value:
+        _check(_lib.rtm_grid_build(arr, n, ctr, half, cells_per_side, _ptr(offsets), _ptr(tri_idx), need.value, C.byref(need)))
+    return offsets, tri_idx
 
 
 def tonemap_device(d_rgb: int, n_pixels: int, gamma: bool, d_rgb8: int, stream: int = 0):
