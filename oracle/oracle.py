@@ -54,6 +54,7 @@ def lib():
         L.orc_model_export.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_add_triangles.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                         C.c_void_p, C.c_char_p, C.c_int]
+        L.orc_trace_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_trace.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int]
@@ -169,6 +170,14 @@ class OracleScene:
         nrm = np.zeros((n, 3))
         lib().orc_trace(self._h, n, _p(rays6), _p(obj), _p(tri), _p(t), _p(nrm), int(faithful))
         return dict(obj_id=obj, tri_id=tri, t=t, normal=nrm)
+
+    def trace_counters(self, ray6) -> dict:
+        """Work counters of ONE hit() query (cells visited, triangle tests, ...)."""
+        ray6 = np.ascontiguousarray(ray6, dtype=np.float64).reshape(6)
+        cnt = np.zeros(9, dtype=np.uint64)
+        lib().orc_trace_counters(self._h, _p(ray6), _p(cnt))
+        return dict(zip(("rays_camera", "rays_bounce", "rays_shadow", "sphere_tests", "plane_tests", "bbox_tests",
+                         "cells_visited", "tri_tests", "model_hits"), (int(v) for v in cnt)))
 
     def shoot(self, uv: np.ndarray) -> np.ndarray:
         uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)

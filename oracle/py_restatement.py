@@ -113,7 +113,7 @@ class Model:
         p = self.pos[i]
         return (p[0], p[1], p[2]), (p[3], p[4], p[5]), (p[6], p[7], p[8])
 
-    def ray_intersect(self, o, d):                                      # core.rs:94-178
+    def ray_intersect(self, o, d, visited=None):                        # core.rs:94-178 (visited: list that receives the cells walked)
         tb = box_intersect(self.center, self.half, o, d)
         if tb is None: return None
         P0 = at(o, d, tb)
@@ -133,6 +133,7 @@ class Model:
         best = None
         while 0 <= idx[0] < n and 0 <= idx[1] < n and 0 <= idx[2] < n:                              # core.rs:129-135
             cell = idx[2] * n * n + idx[1] * n + idx[0]                                             # model.rs:219
+            if visited is not None: visited.append(tuple(idx))
             start = self.offsets[cell - 1] if cell > 0 else 0
             for k in range(start, self.offsets[cell]):
                 ti = self.tri_idx[k]

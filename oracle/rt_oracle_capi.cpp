@@ -219,6 +219,19 @@ int orc_trace(void* hp, uint64_t n, const double* rays6, uint32_t* obj_id, uint3
     return 0;
 }
 
+// one ray through hit (core.rs:68-92) with the work counters of that query alone (known-answer tests of the DDA)
+int orc_trace_counters(void* hp, const double* ray6, uint64_t* counters9) {
+    const Scene& sc = ((Handle*)hp)->img.scene;
+    const Ray r{v3(ray6[0], ray6[1], ray6[2]), v3(ray6[3], ray6[4], ray6[5])};
+    RaycastResult res;
+    Counters c;
+    const bool h = hit(sc, r, res, false, &c);
+    const uint64_t v[9] = {c.rays_camera, c.rays_bounce, c.rays_shadow, c.sphere_tests, c.plane_tests, c.bbox_tests, c.cells_visited,
+                           c.tri_tests, c.model_hits};
+    for (int i = 0; i < 9; ++i) counters9[i] = v[i];
+    return h ? 1 : 0;
+}
+
 // camera rays for given (u,v) pairs (camera.rs:46-52)
 void orc_shoot(void* hp, uint64_t n, const double* uv2, double* rays6) {
     const Camera& c = ((Handle*)hp)->img.camera;

@@ -61,3 +61,71 @@ def test_cpp_oracle_equals_python_restatement(name, oracle_scene):
         for a, b in zip(nn, c["normal"][i].tolist()):
             assert (a == b) or (math.isnan(a) and math.isnan(b)), (i, nn, c["normal"][i])
     assert (c["obj_id"] != NO_ID).mean() > 0.05
+
+
+# ---- the rest of the program path: front end (parser, OBJ, Mat4, Model::new, create_grid, Camera) and shading (pixel loop,
+# ---- cast, get_bounce_direction), restated a second time in oracle/py_program.py from the Rust lines
+def _bits(a):
+    return np.asarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def py_scenes():
+    import py_program as G
+    from conftest import ASSETS, scene_path
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = G.ParsedScene(open(scene_path(name)).read(), ASSETS)
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_python_front_end_equals_cpp_oracle(name, oracle_scene, py_scenes):
+    """Scene file + OBJ -> flattened scene, twice: every f64 of the camera, the primitives, the lights, the materials, the
+    models' boxes, transformed positions and normals, and the grid arrays must be equal.  The list counts are SURVEY 8a's
+    (44,343 for the bunny, 32,420 for the monkey: only right with Box3::include's quirk, box3D.rs:31-45)."""
+    o, s = oracle_scene(name), py_scenes(name)
+    assert (o.width, o.height, o.n_objects, o.n_lights) == (s.width, s.height, len(s.objects), len(s.lights))
+    cam = o.camera()
+    assert np.array_equal(_bits(cam), _bits(list(s.camera.position) + list(s.camera.forward) + list(s.camera.up) + list(s.camera.right) + [s.camera.zoom]))
+    for li, (p, c, r) in enumerate(s.lights):
+        assert np.array_equal(_bits(o.light(li)), _bits(list(p) + list(c) + [r]))
+    for oi, ob in enumerate(s.objects):
+        kind, abcd, col, mt = o.object(oi)
+        assert np.array_equal(_bits(col), _bits(s.materials[oi][0])) and bool(mt) == s.materials[oi][1]
+        if ob[0] != "model":
+            assert kind == (0 if ob[0] == "sphere" else 1)
+            assert np.array_equal(_bits(abcd), _bits(list(ob[1]) + [ob[2]]))
+            continue
+        assert kind == 2
+        m, pm = o.model(oi), ob[1]
+        assert np.array_equal(_bits(m["bbox_center"]), _bits(pm.center)) and np.array_equal(_bits(m["bbox_half"]), _bits(pm.half))
+        assert m["n_tris"] == pm.n_triangles() and m["cells_per_side"] == 32
+        assert np.array_equal(m["offsets"], np.array(ob[2], dtype=np.uint64))
+        assert np.array_equal(m["tri_idx"], np.array(ob[3], dtype=np.uint64))
+        assert len(ob[3]) == {"bunny": 44343, "suzanne": 32420}[name]
+        pos = np.array([[c for v in pm.get_triangle(i) for c in v] for i in range(pm.n_triangles())])
+        nrm = np.array([[c for v in pm.get_triangle_normals(i) for c in v] for i in range(pm.n_triangles())])
+        assert np.array_equal(_bits(m["pos"]), _bits(pos)), "Model::get_triangle differs"
+        same = (_bits(m["nrm"]) == _bits(nrm)) | (np.isnan(m["nrm"]) & np.isnan(nrm))
+        assert same.all(), "Model::get_triangle_normals differs"
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_python_cast_equals_cpp_oracle(name, oracle_scene, py_scenes):
+    """>= 10^4 samples per scene through the whole pixel loop (jitter, shoot_to, cast with shadow rays and bounces, the
+    /spp accumulation): every f64 of the colour equal.  100 x 100 pixels at 1 spp, and a few pixels at 3 spp."""
+    import py_program as G
+    o, s = oracle_scene(name), py_scenes(name)
+    objs = s.hit_objects()
+    size = 100
+    c = o.render(spp=1, seed=7, width=size, height=size)["rgb"]
+    mine = np.array([[G.render_pixel(s, objs, x, y, 1, 7, size, size) for x in range(size)] for y in range(size)])
+    bad = (_bits(c) != _bits(mine)).any(axis=2)
+    assert not bad.any(), f"{int(bad.sum())} of {size * size} pixels differ, first at (y, x) = {tuple(np.argwhere(bad)[0])}"
+    c3 = o.render(spp=3, seed=2, width=24, height=18)["rgb"]
+    for (x, y) in ((0, 0), (11, 9), (23, 17), (5, 12), (17, 3)):
+        assert np.array_equal(_bits(c3[y, x]), _bits(G.render_pixel(s, objs, x, y, 3, 2, 24, 18)))
