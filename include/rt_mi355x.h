@@ -200,7 +200,10 @@ int rtm_trace_rays(const rtm_scene_dev* scene, uint64_t n, const double* rays6, 
                    uint32_t* out_tri_id, double* out_t, double* out_normal3);
 
 /* Framebuffer -> 8-bit RGB with the reference's rule (main.rs:33-48,176-185): optional gamma
- * c>0 ? c^(1/2.2) : 0, then (c*255.0) saturating-truncating cast.  d_rgb, d_rgb8: device pointers. */
+ * c>0 ? c^(1/2.2) : 0, then (c*255.0) saturating-truncating cast.  d_rgb, d_rgb8: device pointers.
+ * Without gamma the bytes are exactly the reference's.  With gamma the power is the device's pow(), the reference's is
+ * the host libm's powf: a value that lands within an ulp of a multiple of 1/255 can come out one code value apart, so the
+ * gamma path (here, in rtm_render_rgb8 and in rtm_cli_main --gamma-correction) is NOT bit-pinned: at most +-1 per byte. */
 int rtm_tonemap_device(const double* d_rgb, uint64_t n_pixels, int gamma, uint8_t* d_rgb8, void* stream);
 
 /* main.rs:153-185 in one call for callers that only want the 8-bit image: renders like

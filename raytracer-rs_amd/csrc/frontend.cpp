@@ -607,6 +607,13 @@ int rtm_frontend_add_triangles(rtm_frontend* fe, uint64_t n_tris, const float* p
                                uint32_t mat_type, const double* transform16) {
     if (!fe || !pos9 || !nrm9 || !color3 || n_tris == 0 || n_tris > 0x7FFFFFFFull / 3)
         return rtm_internal_fail(RTM_ERR_INVALID, "rtm_frontend_add_triangles: bad argument");
+    const size_t models_before = fe->models.size();
+    const uint32_t objects_before = fe->n_objects;
+    auto roll_back = [&]() {  // a failure half way must leave the scene and its C view as they were
+        while (fe->models.size() > models_before) fe->models.pop_back();
+        fe->n_objects = objects_before;
+        fe->refresh_view();
+    };
     try {
         Mesh mesh;
         mesh.vpos.assign(pos9, pos9 + n_tris * 9);
@@ -624,10 +631,10 @@ int rtm_frontend_add_triangles(rtm_frontend* fe, uint64_t n_tris, const float* p
         fe->models.back().obj = fe->n_objects++;
         fe->refresh_view();
     } catch (const FrontError& e) {
-        fe->models.pop_back();
-        fe->refresh_view();
+        roll_back();
         return rtm_internal_fail(e.code, e.msg);
-    } catch (const std::exception& e) {
+    } catch (const std::exception& e) {  // (e.g. std::bad_alloc)
+        roll_back();
         return rtm_internal_fail(RTM_ERR_INVALID, e.what());
     }
     return RTM_OK;

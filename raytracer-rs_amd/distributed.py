@@ -38,7 +38,9 @@ def gather_frame(local_rows: torch.Tensor, height: int, width: int, rank: int, w
         gathered, frame = scratch["gathered"], scratch["frame"]
         dist.gather(pad, list(gathered.unbind(0)), dst=0)
         if deinterleave_device is not None and height % world == 0 and gathered.is_cuda and gathered.dtype == torch.float64:
-            deinterleave_device(gathered.data_ptr(), width, height, world, frame.data_ptr())
+            # on the stream the gather was queued on: rtm's launches do not wait for the null stream
+            deinterleave_device(gathered.data_ptr(), width, height, world, frame.data_ptr(),
+                                stream=torch.cuda.current_stream(gathered.device).cuda_stream)
         else:
             for g in range(world):
                 n = rows_of_rank(height, g, world)
