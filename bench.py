@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override width=height (0 = scene file's size)")
     ap.add_argument("--soup-tris", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the extra pass with one chunk in flight (rocprofv3 runs: every launch of the process is then in the "
+                         "regime of the timed steps, and the profiler's average kernel duration is comparable with roofline.kernel_ms)")
+    ap.add_argument("--streams", type=int, default=2, help="chunks of a frame in flight at once (rtm_set_tuning front_streams; default 2)")
     ap.add_argument("--gather", choices=("f64", "u8"), default="f64",
                     help="N > 1: what rank 0 collects -- the f64 framebuffer (default, the parity path) or the 8-bit image "
                          "after the device tonemap (main.rs:173-185; an eighth of the bytes)")
@@ -132,6 +136,7 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     rtm.init(local_rank)
+    rtm.set_tuning("front_streams", args.streams)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -207,23 +212,25 @@ def main():
     # ... once more with ONE chunk of the frame in flight at a time: no other kernel runs beside the one being timed, so
     # these durations add up to less than the frame (the default, two chunks on two internal streams, overlaps the late
     # rounds of one chunk with the heavy rounds of the other: faster frames, but each launch is stretched by its neighbour)
-    progress("... and with one chunk of the frame in flight at a time")
-    rtm.set_tuning("front_streams", 1)
     iso_steps = max(1, min(args.steps, 5))
-    step()
-    barrier()
-    rtm.timed_events_collect()
-    t0 = time.perf_counter()
-    for _ in range(iso_steps):
+    iso_ms, iso_n, iso_frame_ms = 0.0, 0, None
+    if not args.no_isolated:
+        progress("... and with one chunk of the frame in flight at a time")
+        rtm.set_tuning("front_streams", 1)
         step()
-    barrier()
-    iso_frame_ms = (time.perf_counter() - t0) / iso_steps * 1e3
-    iso_ms, iso_n = rtm.timed_events_collect()
+        barrier()
+        rtm.timed_events_collect()
+        t0 = time.perf_counter()
+        for _ in range(iso_steps):
+            step()
+        barrier()
+        iso_frame_ms = (time.perf_counter() - t0) / iso_steps * 1e3
+        iso_ms, iso_n = rtm.timed_events_collect()
     rtm.set_tuning("front_timed_events", 0)
     # ... and the per-kernel split of one frame (still one chunk at a time) plus the counters of the work really done
     progress("per-kernel split and work counters")
     prof = scene.profile_render_device(p_local, local.data_ptr(), stream=stream.cuda_stream)
-    rtm.set_tuning("front_streams", 2)
+    rtm.set_tuning("front_streams", args.streams)
     frame_ms = scene.time_render_device(p_local, local.data_ptr(), max(1, min(args.steps, 10)), stream=stream.cuda_stream)
 
     if rank == 0:
@@ -262,22 +269,22 @@ def main():
                                     "the oracle's). The device path answers shadow rays whose light is behind the surface (main.rs:96 "
                                     "fails) without tracing them: rays_issued is what it does issue, and of those only the rays that "
                                     "enter a model's box reach the trace kernel: rays_traced (both on this rank)",
-                       "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if world > 1 else "")},
+                       "front_streams": args.streams, "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>" if single else
                          ("rtf::front_trace_kernel<false, true, true>" if args.workload == "soup" else "rtf::front_trace_kernel<false, true, false>"),
                          "bytes_are": "algorithmic (SURVEY 8d: 88 B per traced ray + 8 B per cell + 76 B per triangle test), not measured; "
                                       "`traffic` is the measured HBM figure",
                          "kernel_ms": kern_ms, "kernel_launches_timed": ev_n, "launches_per_frame": n_launch,
-                         "kernel_ms_isolated": kern_ms_iso, "isolated_launches_timed": iso_n, "isolated_frame_ms": iso_frame_ms,
-                         "frac_isolated": frame_bytes / n_launch_iso / (kern_ms_iso * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "launches_per_frame_isolated": n_launch_iso,
+                         "kernel_ms_isolated": kern_ms_iso if iso_n else None, "isolated_launches_timed": iso_n, "isolated_frame_ms": iso_frame_ms,
+                         "frac_isolated": frame_bytes / n_launch_iso / (kern_ms_iso * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_n else None,
+                         "launches_per_frame_isolated": n_launch_iso if iso_n else None,
                          "algorithmic_bytes_per_launch": abytes,
                          "binding_limit": "VALU issue (f64 triangle tests, f32 box screen) and vector-memory latency of per-lane gathers: "
                                           "the scene and the queues of a round are L2/MALL-resident, see valu and DESIGN.md"},
             "valu": {"achieved_tflops": flops / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
                      "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "algorithmic_flops_per_launch": flops},
-            "pipeline": {"frame_ms": frame_ms, "one_chunk_at_a_time": True, "shade_ms": prof["shade_ms"], "trace_ms": prof["trace_ms"],
+            "pipeline": {"frame_ms": frame_ms, "one_chunk_at_a_time": (not args.no_isolated) or args.streams == 1, "shade_ms": prof["shade_ms"], "trace_ms": prof["trace_ms"],
                          "resolve_ms": prof["resolve_ms"], "shade_launches": prof["shade_launches"], "trace_launches": prof["trace_launches"],
                          "traced_rays": prof["traced_rays"], "cells_visited": prof["cells_visited"], "tri_tests": prof["tri_tests"]},
         }
