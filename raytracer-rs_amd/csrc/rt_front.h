@@ -5,8 +5,8 @@
 //            primitives, the slab test and the DDA initialisation (main.rs:57-132, core.rs:68-125,183-210);
 //     trace  (persistent lanes fed from a queue): the 3D-DDA walk and the triangle tests (core.rs:129-167,
 //            model.rs:43-74) for the rays that entered a model's box.
-// Why (DESIGN.md "Kernel", measurements in profiles/): the single-kernel state machines (rt_wave.h, rt_multi.h)
-// are bound by VALU issue at 25-45 % lane utilisation, because a wave always holds a mix of lanes that shade,
+// Why (DESIGN.md "Kernel", measurements in profiles/): the single-kernel state machine (rt_wave.h; a multi-pixel
+// variant of it was measured in round 1 and dropped) is bound by VALU issue at 25-45 % lane utilisation, because a wave always holds a mix of lanes that shade,
 // walk and test.  Sorting by activity needs a pool much larger than a wave; 288 GB of HBM3E hold the state of
 // tens of millions of paths, so the sort is done through memory: the shade kernel runs with every lane doing
 // the same thing, and the trace kernel's lanes only ever walk or test -- a finished lane pulls the next ray from

@@ -1,4 +1,8 @@
-// rt_wave.h -- the production render kernel: a wave-scheduled path-state machine for gfx950.
+// rt_wave.h -- the single-kernel formulation: a wave-scheduled path-state machine for gfx950.  NOT the product
+// path since round 1: rtm_render* run the ray-front pipeline of rt_front.h.  This kernel stays selectable
+// (RTM_KERNEL=wave, rtm_set_option "kernel") as the fallback for scenes the front path does not take (more than
+// 2^26 list entries, more than 1023 cells per side) and as a second device implementation the parity tests hold
+// against the oracle.
 //
 // Why this shape (DESIGN.md "Kernel"): the per-ray arithmetic is fixed by bit parity with the reference, so
 // throughput is decided by (a) how many of a wavefront's 64 lanes do useful work per issued f64 instruction
