@@ -637,7 +637,8 @@ namespace {
 bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
     // packed cell coordinates and model indices (rt_front.h); one 8-row band of paths must fit the workspace budget
     const uint64_t band_paths = (uint64_t)((p->width + 7) / 8) * 64u * p->spp;
-    return sd->front_ok && sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && band_paths <= (64ull << 20);
+    return sd->front_ok && sd->occ_words.size() <= 0xFFFFu && sd->max_n <= rtf::kMaxCellsPerSide && band_paths <= (64ull << 20) &&
+           p->max_bounces <= rtf::kMaxFrontBounces;  // (the bounce count shares a word with the path's flags)
 }
 
 // words of the seven scene-wide bitmaps when they fit the trace kernel's LDS budget (all of them or none: a probe that
@@ -657,7 +658,10 @@ struct FrontProfile {  // rtm_profile_render_device: event pairs per launch (kin
 
 __global__ void front_sum_items_kernel(const uint32_t* ctr, uint32_t nq, unsigned long long* out) {
     unsigned long long v = 0;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nq; j += gridDim.x * blockDim.x) v += ctr[(size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nq; j += gridDim.x * blockDim.x) {
+        const uint32_t* const c = ctr + (size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS0;
+        v += (unsigned long long)c[0] + c[1] + c[2];
+    }
     v = wave_sum_u64(v);
     if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out, v);
 }
@@ -813,7 +817,8 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 mark(0, false, stream);
                 {
                     const bool tabs = sd->view.n_lights <= (uint32_t)rtf::kShadeLights && sd->view.n_materials <= (uint32_t)rtf::kShadeMats &&
-                                      sd->view.n_models <= (uint32_t)rtf::kShadeModels;
+                                      sd->view.n_models <= (uint32_t)rtf::kShadeModels && sd->view.n_spheres <= (uint32_t)rtf::kShadeSpheres &&
+                                      sd->view.n_planes <= (uint32_t)rtf::kShadePlanes;
                     const size_t slds = tabs ? rtf::kShadeLdsBytes : 0;
                     switch ((stats ? 4 : 0) | (r == 0 ? 2 : 0) | (tabs ? 1 : 0)) {
 #define RTM_SHADE_CASE(v, S_, R_, T_) \
@@ -834,7 +839,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     const int variant = (stats ? 4 : 0) | (all_lds ? 2 : 0) | (sd->n_long_cells ? 1 : 0);
                     switch (variant) {
 #define RTM_TRACE_CASE(v, S_, L_, G_) \
-    case v: hipLaunchKernelGGL((rtf::front_trace_kernel<S_, L_, G_>), dim3(trace_wgs), block, lds, stream, sd->view, A, d_cnt); break;
+    case v: hipLaunchKernelGGL((rtf::front_trace_kernel<S_, L_, G_>), dim3(trace_wgs), block, lds, stream, sd->view, A, r, d_cnt); break;
                         RTM_TRACE_CASE(0, false, false, false) RTM_TRACE_CASE(1, false, false, true)
                         RTM_TRACE_CASE(2, false, true, false) RTM_TRACE_CASE(3, false, true, true)
                         RTM_TRACE_CASE(4, true, false, false) RTM_TRACE_CASE(5, true, false, true)
@@ -851,7 +856,9 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     uint64_t live = 0, items = 0;
                     uint32_t live_max = 0, items_max = 0;
                     for (uint32_t j = 0; j < nq; ++j) {
-                        const uint32_t l = h[(size_t)j * rtf::CT_STRIDE + ((r + 1u) & 1u)], it = h[(size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS];
+                        const uint32_t l = h[(size_t)j * rtf::CT_STRIDE + ((r + 1u) & 1u)];
+                        const uint32_t* const ci = &h[(size_t)j * rtf::CT_STRIDE + rtf::CT_ITEMS0];
+                        const uint32_t it = ci[0] + ci[1] + ci[2];
                         live += l; items += it;
                         live_max = std::max(live_max, l); items_max = std::max(items_max, it);
                     }

@@ -38,8 +38,8 @@ using namespace rtd;
 #endif
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multiplied by 10 in 32 bits
-constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256;  // table sizes the shade kernel keeps in LDS
-constexpr size_t kShadeLdsBytes = (size_t)(kShadeLights * 8 + kShadeMats * 4) * 8 + (size_t)kShadeModels * 2 * 4;
+constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256, kShadeSpheres = 256, kShadePlanes = 64;  // table sizes the shade kernel keeps in LDS
+constexpr size_t kShadeLdsBytes = (size_t)(kShadeLights * 8 + kShadeMats * 4) * 8 + (size_t)(kShadeModels + kShadeSpheres + kShadePlanes) * 2 * 4;
 constexpr int kModelTab = 256;               // models whose grid word the trace kernel keeps in LDS
 constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 10 bits each, biased by one
 
@@ -47,35 +47,45 @@ constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 
 // field f of path p is D[at64(PF_COUNT, f, p)] (likewise U, the query results and the trace items).  A wave's
 // accesses of one iteration are 512-byte runs inside ONE ~10 KB region; with whole-frame SoA arrays (hundreds of MB
 // apart) every field sat on its own page and address translation, not HBM, set the pace of the shade kernel.
+// Only what the next round cannot recompute travels: 13 doubles and 4 words per live path in scenes with at most two
+// lights (the fields behind PF_EFF / PU_HOME exist for scenes with more, where a vertex waits through several rounds).
 enum : int {
     PF_COL = 0,    // colour accumulated along the path (main.rs:59)
     PF_ATT = 3,    // attenuation so far
     PF_O = 4,      // origin shared by the path's queries: the camera or the vertex being shaded
     PF_D0 = 7,     // direction of the camera / bounce query
     PF_BA0 = 10,   // its closest analytic hit (spheres, planes)
-    PF_SBA = 11,   // closest analytic hits of the two shadow queries
-    PF_NRM = 13,   // shading normal of the vertex being shaded
-    PF_DIFF = 16,  // diffuse sum so far (scenes with more than two lights)
-    PF_HELD = 19,  // t of slot 0's model hit, kept while further batches of shadow rays are traced (more than two lights)
+    PF_EFF = 11,   // dot(direction to the light, shading normal) of the two shadow queries (main.rs:95): all that the
+                   // consuming round needs of the normal
+    PF_NRM = 13,   // (more than two lights) shading normal of the vertex being shaded: further batches of lights need it
+    PF_DIFF = 16,  // (more than two lights) diffuse sum so far
+    PF_HELD = 19,  // (more than two lights) t of slot 0's model hit, kept while further batches of shadow rays are traced
     PF_COUNT = 20
 };
-enum : int { PU_FL = 0, PU_CTR = 1, PU_HOBJ = 2, PU_HMAT = 3, PU_HKP = 4, PU_MAT = 5, PU_HOME = 6 /* slot in round 0: names pixel and sample */,
-             PU_HTRI = 7, PU_HM = 8 /* with PF_HELD */, PU_COUNT = 9 };
+enum : int { PU_FLB = 0 /* FB_* flags | bounce << FB_BOUNCE_SHIFT */, PU_HKP = 1 /* slot 0's analytic hit: kind << 30 | primitive */, PU_MAT = 2,
+             PU_HOME = 3 /* slot in round 0: names pixel and sample */, PU_LI = 4, PU_HTRI = 5, PU_HM = 6 /* (more than two lights) */, PU_COUNT = 7 };
 enum : uint32_t {
     FB_HASV = 1u,                              // a shaded vertex waits for its shadow results
-    FB_FOUND0 = 2u, FB_FOUND1 = 4u, FB_FOUND2 = 8u,  // query j has an analytic hit
-    FB_TQ0 = 16u, FB_TQ1 = 32u, FB_TQ2 = 64u,        // query j went to the trace kernel: res_*[3p+j] holds its model hit
-    FB_C1 = 128u, FB_C2 = 256u,                      // shadow query j faces its light (eff > 0.001, main.rs:96)
-    FB_NSH_SHIFT = 9u,                               // two bits: shadow queries in flight (0..2)
-    FB_HELD = 2048u                                  // slot 0's answer is in PF_HELD / PU_HTRI / PU_HM
+    FB_FOUND0 = 2u,                            // the path query has an analytic hit (PF_BA0, PU_HKP)
+    FB_TQ0 = 16u, FB_TQ1 = 32u, FB_TQ2 = 64u,  // query j went to the trace kernel: its answer is the next one of region j of the wave's result list
+    FB_C1 = 128u, FB_C2 = 256u,                // shadow query j can contribute: it faces its light (eff > 0.001, main.rs:96) and no sphere or
+                                               // plane stands between (that occlusion is decided when the ray is made, see issue())
+    FB_NSH_SHIFT = 9u,                         // two bits: shadow queries in flight (0..2)
+    FB_HELD = 2048u,                           // slot 0's answer is in PF_HELD / PU_HTRI / PU_HM
+    FB_BOUNCE_SHIFT = 12u                      // the path's bounce count (16 bits) rides in the same word
 };
-// trace items, structure of arrays over the item index
-enum : int { IT_O = 0, IT_D = 3, IT_TM = 6, IT_TD = 9, IT_DCOUNT = 12 };
-enum : int { IU_CELL = 0, IU_Q = 1, IU_M = 2, IU_COUNT = 3 };
+constexpr uint32_t kMaxFrontBounces = 0xFFFFu;
+// trace items, structure of arrays over the item index.  The origin is not in the item: all queries of a path start at
+// PF_O of the state the shade kernel has just written, and the item names that slot.
+enum : int { IT_D = 0, IT_TM = 3, IT_TD = 6, IT_DCOUNT = 9 };
+enum : int { IU_CELL = 0, IU_P = 1, IU_M = 2, IU_COUNT = 3 };
 enum : uint32_t { IM_SX = 1u << 16, IM_SY = 1u << 17, IM_SZ = 1u << 18 };
 // device counters, one set per sub-queue (each written by the one wave that owns the sub-queue)
 // (CT_CLAIM is the one word several waves touch: the trace kernel's waves claim runs of a sub-queue's items from it)
-enum : int { CT_LIVE0 = 0, CT_LIVE1 = 1, CT_ITEMS = 2, CT_CLAIM = 3, CT_STRIDE = 4 };
+// A sub-queue has three REGIONS of cap_l items, one per query slot j: item n of region j sits at sq * cap_i + j * cap_l + n and
+// its answer goes to res[] at the same index.  Within a region items are in path order, so the shade wave of the next
+// round finds the answers of its paths by counting FB_TQj flags as it goes -- no result slot per path, no query id.
+enum : int { CT_LIVE0 = 0, CT_LIVE1 = 1, CT_CLAIM = 2, CT_ITEMS0 = 3 /* .. +2 */, CT_STRIDE = 8 };
 
 struct __attribute__((aligned(16))) FrontResult {  // one 16-byte store per traced ray
     double t;
@@ -101,12 +111,12 @@ struct FrontArgs {
     double* D[2];               // path state, streamed from one buffer to the other every round
     uint32_t* U[2];
     double* fin;                // [at64(3, c, home slot)]: colour of a finished sample
-    FrontResult* res;           // [at64(3, slot, path)]: what the trace kernel found for a query
+    FrontResult* res;           // [item index]: what the trace kernel found for the query of that item
     double* itD;
     uint32_t* itU;
     uint32_t cap_items;         // nq * cap_i: stride of the item arrays
     uint32_t nq;                // sub-queues: wave w of the shade kernel reads live sub-list w % nq and appends to the same one
-    uint32_t cap_l, cap_i;      // capacity of one live sub-list / one item sub-queue (cap_i = 3 * cap_l)
+    uint32_t cap_l, cap_i;      // capacity of one live sub-list / one item sub-queue (cap_i = 3 * cap_l: a region of cap_l per query slot)
     uint32_t* ctr;              // [nq][CT_STRIDE]
 };
 
@@ -140,15 +150,27 @@ template <bool STATS, bool ROUND0, bool TABS>
 __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
                                                               uint32_t* __restrict__ out_tri, unsigned long long* __restrict__ out_cnt) {
     const uint32_t lane = threadIdx.x & 63u;
-    extern __shared__ double sh_tab[];  // [kShadeLights * 8] lights, [kShadeMats * 4] materials, then [kShadeModels * 2] u32 (object, material)
+    // [kShadeLights * 8] lights, [kShadeMats * 4] materials, then u32 pairs: [kShadeModels] (object, material) of the models and
+    // [kShadeSpheres + kShadePlanes] (material, object) of the spheres and the planes
+    extern __shared__ double sh_tab[];
     if (TABS) {
         uint32_t* const sh_mod = (uint32_t*)(sh_tab + kShadeLights * 8 + kShadeMats * 4);
+        uint32_t* const sh_ids = sh_mod + kShadeModels * 2;
         for (uint32_t i = threadIdx.x; i < S.n_lights * 8u; i += kBlock) sh_tab[i] = S.lights[i];
         for (uint32_t i = threadIdx.x; i < S.n_materials * 4u; i += kBlock) sh_tab[kShadeLights * 8 + i] = S.materials[i];
         for (uint32_t i = threadIdx.x; i < S.n_models; i += kBlock) { sh_mod[i * 2] = S.models[i].obj; sh_mod[i * 2 + 1] = S.models[i].mat; }
+        for (uint32_t i = threadIdx.x; i < S.n_spheres * 2u; i += kBlock) sh_ids[i] = S.sph_ids[i];
+        for (uint32_t i = threadIdx.x; i < S.n_planes * 2u; i += kBlock) sh_ids[kShadeSpheres * 2 + i] = S.pl_ids[i];
         __syncthreads();
     }
     const uint32_t* const sh_mod = (const uint32_t*)(sh_tab + kShadeLights * 8 + kShadeMats * 4);
+    const uint32_t* const sh_ids = sh_mod + kShadeModels * 2;
+    // (material, object) of an analytic primitive named by kind << 30 | index: not carried with the path, looked up when its hit is taken
+    auto prim_ids = [&](uint32_t kp, uint32_t& mt, uint32_t& obj) __attribute__((always_inline)) {
+        const uint32_t prim = kp & 0x3FFFFFFFu, plane = kp >> 30;  // (kind 0 or 1 here)
+        if (TABS) { const uint32_t at = (plane ? (uint32_t)kShadeSpheres : 0u) * 2u + prim * 2u; mt = sh_ids[at]; obj = sh_ids[at + 1u]; }
+        else { const uint32_t* const t = (plane ? S.pl_ids : S.sph_ids) + (size_t)prim * 2; mt = t[0]; obj = t[1]; }
+    };
     auto light_at = [&](uint32_t i, int c) -> double { return TABS ? sh_tab[i * 8u + c] : S.lights[(size_t)i * 8 + c]; };
     auto light3 = [&](uint32_t i, int c) -> V3 { return mk(light_at(i, c), light_at(i, c + 1), light_at(i, c + 2)); };
     auto mat_at = [&](uint32_t i, int c) -> double { return TABS ? sh_tab[kShadeLights * 8 + i * 4u + c] : S.materials[(size_t)i * 4 + c]; };
@@ -169,7 +191,9 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
     // field per sector -- and no list of live path ids is needed.
     const uint32_t sq = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     uint32_t* const my_ctr = A.ctr + (size_t)sq * CT_STRIDE;
-    uint32_t n_live_local = 0, n_items_local = 0;  // wave-uniform
+    uint32_t n_live_local = 0;                       // wave-uniform
+    uint32_t n_items0 = 0, n_items1 = 0, n_items2 = 0;  // items appended to the three regions of the wave's sub-queue
+    uint32_t n_res0 = 0, n_res1 = 0, n_res2 = 0;        // answers of the previous round consumed so far, per region
     // round 0: the wave's paths are the 64-path blocks k * nq + sq (sample, tile), dealt round-robin for balance
     const uint32_t blocks_total = (A.np + 63u) / 64u;
     const uint32_t n_in_list = ROUND0 ? ((blocks_total + A.nq - 1u - sq) / A.nq) * 64u : my_ctr[round & 1u];
@@ -184,11 +208,16 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
     uint64_t n_culled = 0;  // STATS: shadow queries answered without a ray (their light is behind the surface)
 
+    // The flag word of a path is read one iteration ahead: which of the previous round's answers exist (and so where
+    // they are) is known when the iteration's loads are issued, instead of one memory latency later.
+    uint32_t flb_next = (!ROUND0 && lane < n_in_list) ? Uin[at64(PU_COUNT, PU_FLB, (size_t)sq * A.cap_l + lane)] : 0u;
     for (uint32_t k = 0; k * 64u < n_in_list; ++k) {  // wave-uniform trip count
         const uint32_t idx = k * 64u + lane;
         bool valid = idx < n_in_list;
         const uint32_t p = sq * A.cap_l + (valid ? idx : 0u);  // slot read this round
         if (ROUND0) valid = (k * A.nq + sq) < blocks_total;
+        const uint32_t flb = flb_next;
+        flb_next = (!ROUND0 && idx + 64u < n_in_list) ? Uin[at64(PU_COUNT, PU_FLB, (size_t)p + 64u)] : 0u;
         auto ldD = [&](int f) -> double { return Din[at64(PF_COUNT, f, p)]; };
         auto ldD3 = [&](int f) -> V3 { return mk(ldD(f), ldD(f + 1), ldD(f + 2)); };
         auto ldU = [&](int f) -> uint32_t { return Uin[at64(PU_COUNT, f, p)]; };
@@ -208,9 +237,9 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         bool cont = false;  // the path stays alive
         bool go0 = false, go1 = false, go2 = false;
         V3 o = mk(0, 0, 0), dir0 = mk(0, 0, 1), nn = mk(0, 0, 1), col = mk(0, 0, 0), diff = mk(0, 0, 0);
-        double att = 1.0, ba0 = 0.0, sba0 = 0.0, sba1 = 0.0, held_t = 0.0;
+        double att = 1.0, ba0 = 0.0, eff0 = 0.0, eff1 = 0.0, held_t = 0.0;
         uint32_t fl = 0, bounce = 0, li = 0, n_sh = 0, mat = 0, held_tri = kNoId, held_m = kNoId;
-        uint32_t h_obj = kNoId, h_mat = 0, h_kp = 0, h_tri = kNoId;  // slot 0's analytic hit (travels on while its result is pending)
+        uint32_t h_obj = kNoId, h_mat = 0, h_kp = 0, h_tri = kNoId;  // slot 0's hit (h_kp travels on while the model answer is pending)
         double best0 = 0.0;
         bool found0 = false;
 
@@ -233,23 +262,37 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
             } else {
                 // ---- every load this round can need, issued before anything is decided: the kernel moves ~0.5 KB per
                 //      path and is bound by memory latency, not by the few bytes a path in another state would skip
-                fl = ldU(PU_FL);
-                const uint32_t ctr = ldU(PU_CTR);
+                fl = flb & ((1u << FB_BOUNCE_SHIFT) - 1u);
+                bounce = flb >> FB_BOUNCE_SHIFT;
                 o = ldD3(PF_O);
                 ba0 = ldD(PF_BA0);
-                h_obj = ldU(PU_HOBJ); h_mat = ldU(PU_HMAT); h_kp = ldU(PU_HKP);
+                h_kp = ldU(PU_HKP);
                 mat = ldU(PU_MAT);
-                FrontResult r0 = A.res[at64(3, 0, p)];
-                const FrontResult l_r1 = A.res[at64(3, 1, p)], l_r2 = A.res[at64(3, 2, p)];
-                if (nL > 2u) { held_t = ldD(PF_HELD); held_tri = ldU(PU_HTRI); held_m = ldU(PU_HM); }  // (only then can a result be held)
-                sba0 = ldD(PF_SBA); sba1 = ldD(PF_SBA + 1);
-                nn = ldD3(PF_NRM);
+                if (nL > 2u) { held_t = ldD(PF_HELD); held_tri = ldU(PU_HTRI); held_m = ldU(PU_HM); li = ldU(PU_LI); }  // (only then can a result be held)
+                eff0 = ldD(PF_EFF); eff1 = ldD(PF_EFF + 1);
+                if (nL > 2u) nn = ldD3(PF_NRM);
                 dir0 = ldD3(PF_D0);
                 col = ldD3(PF_COL);
                 att = ldD(PF_ATT);
                 if (nL > 2u) diff = ldD3(PF_DIFF);
-                bounce = ctr & 0xFFFFu;
-                li = ctr >> 16;
+            }
+        }
+        // ---- the answers of the previous round: the next entry of region j for every path whose flag says it asked
+        //      (a held answer of slot 0 was read in the round after its ray was traced; its flag stays set)
+        FrontResult r0, l_r1, l_r2;
+        r0.t = 0.0; r0.tri = kNoId; r0.model = kNoId;
+        l_r1 = r0; l_r2 = r0;
+        if (!ROUND0) {
+            const bool q0 = valid && (flb & FB_TQ0) && !(flb & FB_HELD), q1 = valid && (flb & FB_TQ1), q2 = valid && (flb & FB_TQ2);
+            const unsigned long long m0 = __ballot(q0), m1 = __ballot(q1), m2 = __ballot(q2), below = (1ull << lane) - 1ull;
+            const size_t rbase = (size_t)sq * A.cap_i;
+            if (q0) r0 = A.res[rbase + n_res0 + (uint32_t)__popcll(m0 & below)];
+            if (q1) l_r1 = A.res[rbase + A.cap_l + n_res1 + (uint32_t)__popcll(m1 & below)];
+            if (q2) l_r2 = A.res[rbase + 2u * A.cap_l + n_res2 + (uint32_t)__popcll(m2 & below)];
+            n_res0 += (uint32_t)__popcll(m0); n_res1 += (uint32_t)__popcll(m1); n_res2 += (uint32_t)__popcll(m2);
+        }
+        if (valid) {
+            if (!ROUND0) {
                 if (fl & FB_HELD) { r0.t = held_t; r0.tri = held_tri; r0.model = held_m; }  // slot 0's answer came in an earlier round
                 // ---- 0. decisions
                 const bool a_v = (fl & FB_HASV) != 0u;
@@ -266,6 +309,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 if (b_take) {
                     best0 = ba0;
                     found0 = (fl & FB_FOUND0) != 0u;
+                    if (found0) prim_ids(h_kp, h_mat, h_obj);
                     if ((fl & FB_TQ0) && r0.model != kNoId) {
                         const uint32_t m = r0.model;
                         const double t = r0.t;
@@ -294,18 +338,19 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 //      produced the ray -- rather than carried through memory.
                 if (n_in > 0u) {
                     if (li == 0u) diff = mk(0, 0, 0);
-                    auto shade = [&](const uint32_t j, const double sba, const uint32_t rm, const double rt) __attribute__((always_inline)) {
+                    // main.rs:86-93 takes the closest hit of the shadow ray and asks whether it lies before the light:
+                    // sqdist(ray_at(o, dir, t), o) <= dl2.  That predicate can only go from true to false as t grows (every
+                    // operation in it is monotonic in t for t > 0, rounding included), so "the closest hit occludes" equals
+                    // "some hit occludes": the spheres and planes were asked when the ray was made (issue(): FB_C is clear if
+                    // one of them occludes), the models' closest hit is asked here.
+                    auto shade = [&](const uint32_t j, const double eff, const uint32_t rm, const double rt) __attribute__((always_inline)) {
                         if (j < n_in && (fl & (FB_C1 << j))) {  // a query that cannot contribute is not looked at
                             const V3 lp = light3(li + j, 0);
                             const V3 dir = normalize(lp - o);
                             const double dl2 = sqdist(o, lp);
-                            double best = sba;
-                            bool found = (fl & (FB_FOUND1 << j)) != 0u;
-                            if ((fl & (FB_TQ1 << j)) && rm != kNoId && !(rt <= kEps) && rt < best) { best = rt; found = true; }
                             bool occluded = false;
-                            if (found) occluded = sqdist(ray_at(o, dir, best), o) <= dl2;
-                            if (!occluded) {
-                                const double eff = dot(dir, nn);  // > 0.001, or FB_C would not be set
+                            if ((fl & (FB_TQ1 << j)) && rm != kNoId && !(rt <= kEps)) occluded = sqdist(ray_at(o, dir, rt), o) <= dl2;
+                            if (!occluded) {  // eff > 0.001, or FB_C would not be set
                                 const double lr = light_at(li + j, 6);
                                 const double dd = fmax(dl2 / (lr * lr), 1.0);
                                 const double decay = 1.0 / dd;
@@ -313,8 +358,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                             }
                         }
                     };
-                    shade(0u, sba0, l_r1.model, l_r1.t);
-                    shade(1u, sba1, l_r2.model, l_r2.t);
+                    shade(0u, eff0, l_r1.model, l_r1.t);
+                    shade(1u, eff1, l_r2.model, l_r2.t);
                     li += n_in;
                 } else if (a_fin) {
                     diff = mk(0, 0, 0);  // a vertex without lights
@@ -389,7 +434,9 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
 
         // ---- a query: analytic primitives (core.rs:183-210), slab test and DDA set-up of the first model whose box
         //      the ray meets (box3D.rs:64-93, core.rs:95-125); that model and the following ones are the trace kernel's
-        auto issue = [&](const uint32_t j, const bool go, const V3 dir) __attribute__((always_inline)) {
+        // Shadow queries (j > 0) bring dl2 = |light - o|^2 and `lit`: a sphere or plane that occludes the light settles the
+        // query here (its flag FB_C stays clear and no ray goes to the models, unless exact work counters are wanted).
+        auto issue = [&](const uint32_t j, const bool go, const V3 dir, const double dl2, const bool lit) __attribute__((always_inline)) {
             bool item = false;
             int ix = 0, iy = 0, iz = 0;
             double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
@@ -442,16 +489,18 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     if (t < kEps) continue;
                     consider(t, pl_ids_c[i * 2 + 1], pl_ids_c[i * 2], (1u << 30) | i);
                 }
+                bool models = true;
                 if (j == 0u) {
                     ba0 = best;
-                    h_obj = b_obj; h_mat = b_mat; h_kp = b_kp;
-                } else if (j == 1u) {
-                    sba0 = best;
+                    h_kp = b_kp;
+                    if (found) fl |= FB_FOUND0;
                 } else {
-                    sba1 = best;
+                    const bool occ = found && sqdist(ray_at(o, dir, best), o) <= dl2;
+                    if (lit && !occ) fl |= FB_C1 << (j - 1u);
+                    models = !occ || !A.cull;
                 }
-                if (found) fl |= FB_FOUND0 << j;
-                {
+                (void)b_mat;
+                if (models) {
                     for (uint32_t m = 0; m < S.n_models && !item; ++m) {
                         const __attribute__((address_space(4))) RtmDevModel& M = models_c[m];
                         if (STATS) cnt.v[C_BBOX]++;
@@ -485,56 +534,56 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
             // append to the wave's trace sub-queue
             const unsigned long long want = __ballot(item);
             if (want) {
-                const uint32_t at = n_items_local;
-                n_items_local += (uint32_t)__popcll(want);
+                uint32_t& n_items_j = j == 0u ? n_items0 : (j == 1u ? n_items1 : n_items2);
+                const uint32_t at = j * A.cap_l + n_items_j;  // region j of the wave's sub-queue
+                n_items_j += (uint32_t)__popcll(want);
                 if (item) {
                     const size_t it = (size_t)sq * A.cap_i + at + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
                     double* const I = A.itD;
-                    I[at64(IT_DCOUNT, IT_O + 0, it)] = o.x; I[at64(IT_DCOUNT, IT_O + 1, it)] = o.y; I[at64(IT_DCOUNT, IT_O + 2, it)] = o.z;
                     I[at64(IT_DCOUNT, IT_D + 0, it)] = dir.x; I[at64(IT_DCOUNT, IT_D + 1, it)] = dir.y; I[at64(IT_DCOUNT, IT_D + 2, it)] = dir.z;
                     I[at64(IT_DCOUNT, IT_TM + 0, it)] = tmx; I[at64(IT_DCOUNT, IT_TM + 1, it)] = tmy; I[at64(IT_DCOUNT, IT_TM + 2, it)] = tmz;
                     I[at64(IT_DCOUNT, IT_TD + 0, it)] = tdx; I[at64(IT_DCOUNT, IT_TD + 1, it)] = tdy; I[at64(IT_DCOUNT, IT_TD + 2, it)] = tdz;
                     A.itU[at64(IU_COUNT, IU_CELL, it)] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
-                    A.itU[at64(IU_COUNT, IU_Q, it)] = (p_out << 2) | j;  // query id: the path's next slot, and the query slot
+                    A.itU[at64(IU_COUNT, IU_P, it)] = p_out;  // the path's next slot: where the trace kernel finds the ray's origin
                     A.itU[at64(IU_COUNT, IU_M, it)] = mword;
                 }
             }
         };
-        issue(0u, go0, dir0);
+        issue(0u, go0, dir0, 0.0, false);
         {
             // shadow rays to lights li, li+1 (main.rs:80-85) and what each would add to the diffuse sum (main.rs:96-102)
             auto shadow = [&](const uint32_t j, const bool go) __attribute__((always_inline)) {
                 V3 dir = mk(0, 0, 1);
-                bool trace = false;
+                bool trace = false, lit = false;
+                double dl2 = 0.0;
                 if (go) {
                     const V3 lp = light3(li + j, 0);
                     dir = normalize(lp - o);
+                    dl2 = sqdist(o, lp);
                     const double eff = dot(dir, nn);
-                    const bool lit = eff > 0.001;  // main.rs:96: otherwise the query's answer is never used
-                    if (lit) fl |= FB_C1 << j;
+                    if (j == 0u) eff0 = eff; else eff1 = eff;
+                    lit = eff > 0.001;  // main.rs:96: otherwise the query's answer is never used
                     trace = lit || !A.cull;
                     if (STATS && !trace) n_culled++;
                 }
-                issue(1u + j, go && trace, dir);  // (the host turns culling off when exact work counters are wanted)
+                issue(1u + j, go && trace, dir, dl2, lit);  // (the host turns culling off when exact work counters are wanted)
             };
             shadow(0u, go1);
             shadow(1u, go2);
         }
         if (valid && cont) {  // the state moves on
             stD3(PF_COL, col); stD(PF_ATT, att);
-            stD3(PF_O, o); stD3(PF_D0, dir0); stD3(PF_NRM, nn);
-            stD(PF_BA0, ba0); stD(PF_SBA, sba0); stD(PF_SBA + 1, sba1);
-            if (nL > 2u) { stD(PF_HELD, held_t); stU(PU_HTRI, held_tri); stU(PU_HM, held_m); }
-            if (nL > 2u) stD3(PF_DIFF, diff);
-            stU(PU_FL, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT));
-            stU(PU_CTR, bounce | (li << 16));
-            stU(PU_HOBJ, h_obj); stU(PU_HMAT, h_mat); stU(PU_HKP, h_kp); stU(PU_MAT, mat);
+            stD3(PF_O, o); stD3(PF_D0, dir0);
+            stD(PF_BA0, ba0); stD(PF_EFF, eff0); stD(PF_EFF + 1, eff1);
+            if (nL > 2u) { stD3(PF_NRM, nn); stD3(PF_DIFF, diff); stD(PF_HELD, held_t); stU(PU_HTRI, held_tri); stU(PU_HM, held_m); stU(PU_LI, li); }
+            stU(PU_FLB, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT) | (bounce << FB_BOUNCE_SHIFT));
+            stU(PU_HKP, h_kp); stU(PU_MAT, mat);
             stU(PU_HOME, home);
         }
     }
     if (lane == 0) {
         my_ctr[(round + 1u) & 1u] = n_live_local;
-        my_ctr[CT_ITEMS] = n_items_local;
+        my_ctr[CT_ITEMS0] = n_items0; my_ctr[CT_ITEMS0 + 1] = n_items1; my_ctr[CT_ITEMS0 + 2] = n_items2;
         my_ctr[CT_CLAIM] = 0u;
     }
     flush_counters<STATS>(cnt, out_cnt);
@@ -551,7 +600,7 @@ enum : uint32_t { TS_IDLE = 0, TS_ENTER = 1, TS_TRAV = 2 };
 // ALL_LDS: every model's occupancy bitmap fits the LDS budget (the host checks)
 // HAS_LONG: some cell of some model has more than 32 entries (the box screen exists only in that instantiation)
 template <bool STATS, bool ALL_LDS, bool HAS_LONG = false>
-__global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmDevScene S, FrontArgs A, unsigned long long* __restrict__ out_cnt) {
+__global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmDevScene S, FrontArgs A, uint32_t round, unsigned long long* __restrict__ out_cnt) {
     extern __shared__ uint32_t occ_lds[];  // [A.occ_words]
     __shared__ uint32_t mtab[kModelTab];     // per model: cells per side | first scene cell / 32 << 10 (what a lane keeps in `mw`)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -574,13 +623,18 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     // failed claims; nothing waits on another wave.
     const uint32_t trace_waves = gridDim.x * (kBlock / 64);
     const uint32_t wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
-    uint32_t sq = wave_id, sq_items = 0, stolen = 0;
+    uint32_t sq = wave_id, sq_items = 0, sq_n0 = 0, sq_n01 = 0, stolen = 0;  // items of sub-queue sq: all regions, region 0, regions 0 and 1
     bool stealing = false;
-    uint32_t pool_next = 0, pool_end = 0;  // unread items of the current claim
-    if (sq < A.nq) sq_items = A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
+    uint32_t pool_next = 0, pool_end = 0;  // unread items of the current claim, counted through the sub-queue's three regions
+    auto open_queue = [&]() __attribute__((always_inline)) {  // (wave-uniform)
+        const uint32_t* const c = A.ctr + (size_t)sq * CT_STRIDE + CT_ITEMS0;
+        sq_n0 = c[0]; sq_n01 = sq_n0 + c[1]; sq_items = sq_n01 + c[2];
+    };
+    if (sq < A.nq) open_queue();
     uint32_t steal_max = sq_items >= A.claim ? A.steal : 0u;  // (short queues, late rounds: nothing worth taking)
     const gptr<double> I = as_global(A.itD);
     const gptr<uint32_t> IU = as_global(A.itU);
+    const gptr<double> Pst = as_global(A.D[(round + 1u) & 1u]);  // the path state the shade kernel has just written: the rays' origins
 
     uint32_t st = TS_IDLE, model_i = 0, q = 0, sgn = 0;
     uint32_t mw = 0;  // the model the ray is in: cells per side (10 bits) | first scene cell / 32
@@ -620,7 +674,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         if (STATS) { dg_max_walks = max(dg_max_walks, dg_ray_its & 0xFFFFu); dg_max_tests = max(dg_max_tests, dg_ray_its >> 16); }
         FrontResult r;
         r.t = bt; r.tri = btri; r.model = bm;
-        A.res[at64(3, (int)(q & 3u), q >> 2)] = r;
+        A.res[q] = r;  // q = the item's index
         st = TS_IDLE;
     };
     auto model_result = [&]() __attribute__((always_inline)) {  // the lane's model reports a hit (core.rs:75-83 over the models)
@@ -693,8 +747,8 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         if (lane == 0) at = atomicAdd(A.ctr + (size_t)sq * CT_STRIDE + CT_CLAIM, A.claim);
                         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
                         if (at < sq_items) {
-                            pool_next = sq * A.cap_i + at;
-                            pool_end = sq * A.cap_i + min(at + A.claim, sq_items);
+                            pool_next = at;
+                            pool_end = min(at + A.claim, sq_items);
                             continue;
                         }
                     }
@@ -707,21 +761,24 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         ++stolen;
                         sq = (wave_id + stolen * 2731u) % A.nq;  // (an odd stride: different waves try different sub-queues)
                     }
-                    sq_items = A.ctr[(size_t)sq * CT_STRIDE + CT_ITEMS];
+                    open_queue();
                     continue;
                 }
                 const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 const uint32_t avail = pool_end - pool_next;
                 if (st == TS_IDLE && rank < avail) {
-                    const size_t it = (size_t)pool_next + rank;
-                    o = mk(I[at64(IT_DCOUNT, IT_O + 0, it)], I[at64(IT_DCOUNT, IT_O + 1, it)], I[at64(IT_DCOUNT, IT_O + 2, it)]);
+                    const uint32_t li_ = pool_next + rank;  // position in the sub-queue -> region, position in the region
+                    const uint32_t rg = (li_ >= sq_n0 ? 1u : 0u) + (li_ >= sq_n01 ? 1u : 0u);
+                    const size_t it = (size_t)sq * A.cap_i + (size_t)rg * A.cap_l + (li_ - (rg == 0u ? 0u : (rg == 1u ? sq_n0 : sq_n01)));
+                    const size_t ps = IU[at64(IU_COUNT, IU_P, it)];
                     d = mk(I[at64(IT_DCOUNT, IT_D + 0, it)], I[at64(IT_DCOUNT, IT_D + 1, it)], I[at64(IT_DCOUNT, IT_D + 2, it)]);
                     tmx = I[at64(IT_DCOUNT, IT_TM + 0, it)]; tmy = I[at64(IT_DCOUNT, IT_TM + 1, it)]; tmz = I[at64(IT_DCOUNT, IT_TM + 2, it)];
                     tdx = I[at64(IT_DCOUNT, IT_TD + 0, it)]; tdy = I[at64(IT_DCOUNT, IT_TD + 1, it)]; tdz = I[at64(IT_DCOUNT, IT_TD + 2, it)];
                     const uint32_t cw = IU[at64(IU_COUNT, IU_CELL, it)];
                     ix = (int)(cw & 1023u) - 1; iy = (int)((cw >> 10) & 1023u) - 1; iz = (int)((cw >> 20) & 1023u) - 1;
-                    q = IU[at64(IU_COUNT, IU_Q, it)];
+                    q = (uint32_t)it;
                     const uint32_t iw = IU[at64(IU_COUNT, IU_M, it)];
+                    o = mk(Pst[at64(PF_COUNT, PF_O + 0, ps)], Pst[at64(PF_COUNT, PF_O + 1, ps)], Pst[at64(PF_COUNT, PF_O + 2, ps)]);
                     model_i = iw & 0xFFFFu;
                     sgn = iw;
                     mw = model_i < (uint32_t)kModelTab ? mtab[model_i] : (models_g[model_i].n | ((models_g[model_i].cell_base >> 5) << 10));
