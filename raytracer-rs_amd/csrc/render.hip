@@ -605,15 +605,17 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             (rc = upload(sd, nrm, &D.tri_nrm)) || (rc = upload(sd, occ, &D.occupancy)))
             return fail(rc);
     }
-    {   // the seven bitmaps, each over the cells of all models
+    {   // the seven bitmaps over the cells of all models, interleaved: the words of cells [32 w, 32 w + 32) are words 8 w .. 8 w + 6
+        // (one shift and one OR from cell and arrival direction to the word, no multiply in the walk)
         const size_t W = (size_t)(total_cells / 32);
-        std::vector<uint32_t> occ7_all(W * 7 + 1, 0u);
+        std::vector<uint32_t> occ7_all(W * 8 + 1, 0u);
         for (uint32_t m = 0; m < s->n_models; ++m) {
             const size_t wm = occ7_of_model[m].size() / 7, wbase = models[m].cell_base / 32;
-            for (int a = 0; a < 7; ++a) std::memcpy(occ7_all.data() + (size_t)a * W + wbase, occ7_of_model[m].data() + (size_t)a * wm, wm * 4);
+            for (int a = 0; a < 7; ++a)
+                for (size_t w = 0; w < wm; ++w) occ7_all[(wbase + w) * 8 + (size_t)a] = occ7_of_model[m][(size_t)a * wm + w];
         }
         V.g_occ_dir_words = (uint32_t)W;
-        sd->occ7_words = (uint32_t)std::min<size_t>(W * 7, 0xFFFFFFFFu);
+        sd->occ7_words = (uint32_t)std::min<size_t>(W * 8, 0xFFFFFFFFu);
         g_box8.resize(((g_box8.size() + 3) & ~(size_t)3) + 8, 0u);
         if ((rc = upload(sd, occ7_all, &V.g_occ7)) || (rc = upload(sd, g_info, &V.g_cell_info)) || (rc = upload(sd, g_rec, &V.g_cell_rec)) ||
             (rc = upload(sd, g_frames, &V.g_cell_frame)) || (rc = upload(sd, g_box8, &V.g_cell_box8)))
@@ -645,7 +647,7 @@ bool front_supported(const rtm_scene_dev* sd, const rtm_params* p) {
 // may go either way would wait for both memories)
 uint32_t front_occ_words(const rtm_scene_dev* sd) {
     if (sd->occ7_words <= (uint32_t)rtw::kOccLdsWordsMax) return sd->occ7_words;
-    if (sd->occ7_words / 7u <= (uint32_t)rtw::kOccLdsWordsMax) return sd->occ7_words / 7u;  // the plain occupancy alone
+    if (sd->occ7_words / 8u <= (uint32_t)rtw::kOccLdsWordsMax) return sd->occ7_words / 8u;  // the plain occupancy alone
     return 0u;
 }
 
@@ -801,8 +803,12 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
             A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
             A.occ_words = occ_words;
-            A.occ_dirs = occ_plain_only ? 0u : 1u;
-            A.occ_src_off = occ_plain_only ? 6u * (sd->occ7_words / 7u) : 0u;
+            A.occ_plain = occ_plain_only ? 1u : 0u;
+            // which bitmap word the walk probes (rt_front.h probe()): the arrival direction's, the plain occupancy when
+            // nothing may be skipped (counting build), or the one staged bitmap
+            A.occ_shift = occ_plain_only ? 0u : 3u;
+            A.occ_m1 = (!occ_plain_only && A.cull) ? 7u : 0u;
+            A.occ_m2 = (!occ_plain_only && !A.cull) ? 6u : 0u;
             A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
             A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);
             A.itD = (double*)(B + o_itD); A.itU = (uint32_t*)(B + o_itU);

@@ -41,7 +41,8 @@ constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multipli
 constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256, kShadeSpheres = 256, kShadePlanes = 64;  // table sizes the shade kernel keeps in LDS
 constexpr size_t kShadeLdsBytes = (size_t)(kShadeLights * 8 + kShadeMats * 4) * 8 + (size_t)(kShadeModels + kShadeSpheres + kShadePlanes) * 2 * 4;
 constexpr int kModelTab = 256;               // models whose grid word the trace kernel keeps in LDS
-constexpr uint32_t kMaxCellsPerSide = 1023;  // cell coordinates travel packed, 10 bits each, biased by one
+constexpr uint32_t kMaxCellsPerSide = 512;   // cell coordinates travel packed, 10 bits each, biased by one; the walk's countdown has 9-bit fields
+constexpr uint32_t kRemGuards = (1u << 9) | (1u << 19) | (1u << 29);  // see `rem` in the trace kernel
 
 // Per-path state, array of structures of arrays: paths in blocks of 64, a block's fields back to back, so double
 // field f of path p is D[at64(PF_COUNT, f, p)] (likewise U, the query results and the trace items).  A wave's
@@ -105,9 +106,9 @@ struct FrontArgs {
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
     uint32_t coop;              // trace kernel: 1 = when at most four rays of a wave are testing, the other lanes test their entries
     uint32_t t_test_frac, t_min_lanes;
-    uint32_t occ_words;         // bitmap words the trace kernel stages in LDS, starting at word occ_src_off of g_occ7
-    uint32_t occ_src_off;
-    uint32_t occ_dirs;          // 1: the walk probes the bitmap of its arrival direction; 0: only the plain occupancy is used (and staged)
+    uint32_t occ_words;         // bitmap words the trace kernel stages in LDS: all of g_occ7 (occ_plain = 0) or its plain occupancy alone
+    uint32_t occ_plain;         // 1: only the plain occupancy (slot 6 of every group of eight words) is staged, one word per 32 cells
+    uint32_t occ_shift, occ_m1, occ_m2;  // bitmap word of cell c arriving from direction a: ((c >> 5) << occ_shift) + ((a & occ_m1) | occ_m2)
     double* D[2];               // path state, streamed from one buffer to the other every round
     uint32_t* U[2];
     double* fin;                // [at64(3, c, home slot)]: colour of a finished sample
@@ -602,13 +603,13 @@ enum : uint32_t { TS_IDLE = 0, TS_ENTER = 1, TS_TRAV = 2 };
 template <bool STATS, bool ALL_LDS, bool HAS_LONG = false>
 __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmDevScene S, FrontArgs A, uint32_t round, unsigned long long* __restrict__ out_cnt) {
     extern __shared__ uint32_t occ_lds[];  // [A.occ_words]
-    __shared__ uint32_t mtab[kModelTab];     // per model: cells per side | first scene cell / 32 << 10 (what a lane keeps in `mw`)
+    __shared__ uint32_t mtab[kModelTab];     // per model: cells per side | first scene cell / 32 << 10
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t m = tid; m < min(S.n_models, (uint32_t)kModelTab); m += kBlock)
         mtab[m] = S.models[m].n | ((S.models[m].cell_base >> 5) << 10);
-    {  // stage the seven scene-wide bitmaps (the host passes occ_words = all of them, or 0 when they do not fit)
-        const gptr<uint32_t> src = as_global(S.g_occ7) + A.occ_src_off;
-        for (uint32_t i = tid; i < A.occ_words; i += kBlock) occ_lds[i] = src[i];
+    {  // stage the scene-wide bitmaps (the host passes occ_words = all of them, the plain occupancy alone, or 0 when neither fits)
+        const gptr<uint32_t> src = as_global(S.g_occ7);
+        for (uint32_t i = tid; i < A.occ_words; i += kBlock) occ_lds[i] = src[A.occ_plain ? i * 8u + 6u : i];
     }
     __syncthreads();
     Counters cnt;
@@ -636,27 +637,29 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     const gptr<uint32_t> IU = as_global(A.itU);
     const gptr<double> Pst = as_global(A.D[(round + 1u) & 1u]);  // the path state the shade kernel has just written: the rays' origins
 
-    uint32_t st = TS_IDLE, model_i = 0, q = 0, sgn = 0;
-    uint32_t mw = 0;  // the model the ray is in: cells per side (10 bits) | first scene cell / 32
+    uint32_t st = TS_IDLE, model_i = 0, q = 0;
     const gptr<RtmDevModel> models_g = (gptr<RtmDevModel>)S.models;
     const gptr<uint32_t> cell_info = as_global(S.g_cell_info);
     const gptr<double> cell_rec = as_global(S.g_cell_rec);
     const gptr<double> cell_frame = as_global(S.g_cell_frame);
     const gptr<uint32_t> cell_box8 = as_global(S.g_cell_box8);
     const gptr<uint32_t> occ_glb = as_global(S.g_occ7);
-    const uint32_t occ_dir_words = S.g_occ_dir_words;  // words of one direction's bitmap
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    int ix = 0, iy = 0, iz = 0;
     double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
+    // Where the ray is, in the form the walk needs (nothing is multiplied per step):
+    //   cv  = scene cell << 3 | arrival code (0..5 = the step came along -x,+x,-y,+y,-z,+z; 6 = entry cell, no step yet);
+    //   rem = steps left before the ray leaves the grid, per axis (x | y << 10 | z << 20), with a guard bit above each 9-bit
+    //         field: a step along an axis that has none left borrows its guard, which is the bounds test of core.rs:129-134;
+    //   wx, wy, wz = what a step along each axis adds to cv: (cell index stride, signed) << 3 | arrival code.
+    uint32_t cv = 6u, rem = kRemGuards, wx = 0, wy = 0, wz = 0;
     uint32_t k = 0, k_end = 0, m_tri = 0;  // [k, k_end): the rest of the current cell's list, k = first entry of the 32-entry window
-    uint32_t wmask = 0, arr = 6;           // untested entries of the window; the direction the ray arrived from
+    uint32_t wmask = 0;                    // untested entries of the window
     uint32_t wmask_hi = 0;                 // long cells: the 32 entries behind the window, already screened (F_HI)
     double m_t = 0.0;
     // per-ray flags, kept as bits of one VGPR: as separate bools they live in SGPR lane masks and every join of the
     // divergent control flow below costs a handful of scalar mask merges per flag (half of the kernel's instructions)
     enum : uint32_t {
         F_HAVE = 1u,   // a triangle of the current cell was accepted (core.rs:140-149)
-        F_FRESH = 2u,  // the entry cell has not been visited yet: no DDA step before it
         F_OPEN = 4u,   // the current cell's list is not exhausted
         F_WINIT = 8u,  // the window of a newly opened cell has not been set up yet
         F_LONG = 16u,  // the window belongs to a long cell and has not been screened against the entries' boxes yet
@@ -689,47 +692,54 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
         model_i += 1u;
         if (model_i >= S.n_models) finish_ray(); else st = TS_ENTER;
     };
-#define RTF_DDA_ADVANCE()                                                      \
-    do {                                                                       \
-        const bool ax_ = (tmx < tmy) && (tmx < tmz);                           \
-        const bool ay_ = !(tmx < tmy) && (tmy < tmz);                          \
-        const bool az_ = !ax_ && !ay_;                                         \
-        ix += ax_ ? ((sgn & IM_SX) ? 1 : -1) : 0;                              \
-        iy += ay_ ? ((sgn & IM_SY) ? 1 : -1) : 0;                              \
-        iz += az_ ? ((sgn & IM_SZ) ? 1 : -1) : 0;                              \
-        const double nx_ = tmx + tdx, ny_ = tmy + tdy, nz_ = tmz + tdz;        \
-        tmx = ax_ ? nx_ : tmx;                                                 \
-        tmy = ay_ ? ny_ : tmy;                                                 \
-        tmz = az_ ? nz_ : tmz;                                                 \
-        arr = ax_ ? ((sgn & IM_SX) ? 1u : 0u) : (ay_ ? ((sgn & IM_SY) ? 3u : 2u) : ((sgn & IM_SZ) ? 5u : 4u)); \
-    } while (0)
-
+    // The bitmap probe of the lane's cell (the bitmap of its arrival direction: cells whose entries were all tested one
+    // step ago count as empty; the counting build, and scenes whose bitmaps do not fit in LDS together, use the plain
+    // occupancy -- the host encodes which in occ_shift / occ_m1 / occ_m2).
+    // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one block, the wait before
+    // the bit test would also wait for outstanding global loads.)  The cell's record is read by the next test phase, not
+    // here: a load into registers that an earlier step's load may still be filling makes the compiler wait for all of them.
+    auto probe = [&]() __attribute__((always_inline)) {
+        if (STATS) cnt.v[C_CELLS]++;
+        const uint32_t wi = ((cv >> 8) << A.occ_shift) + ((cv & A.occ_m1) | A.occ_m2);
+        uint32_t word;
+        if (ALL_LDS) word = occ_lds[wi];
+        else word = occ_glb[wi];
+        if ((word >> ((cv >> 3) & 31u)) & 1u) fl |= F_WINIT | F_OPEN;  // non-empty
+    };
+    // Position of a ray that enters cell (ix, iy, iz) of a model with n cells per side whose first scene cell is base32 * 32
+    auto place = [&](const int ix, const int iy, const int iz, const bool px, const bool py, const bool pz, const uint32_t n,
+                     const uint32_t base32) __attribute__((always_inline)) {
+        const uint32_t cell = (base32 << 5) + (((uint32_t)iz * n + (uint32_t)iy) * n + (uint32_t)ix);
+        cv = (cell << 3) | 6u;
+        const uint32_t rx = px ? n - 1u - (uint32_t)ix : (uint32_t)ix, ry = py ? n - 1u - (uint32_t)iy : (uint32_t)iy,
+                       rz = pz ? n - 1u - (uint32_t)iz : (uint32_t)iz;
+        rem = rx | (ry << 10) | (rz << 20) | kRemGuards;
+        const uint32_t nn = n * n;
+        wx = px ? ((1u << 3) | 1u) : ((0u - 1u) << 3);
+        wy = py ? ((n << 3) | 3u) : (((0u - n) << 3) | 2u);
+        wz = pz ? ((nn << 3) | 5u) : (((0u - nn) << 3) | 4u);
+        fl = 0u;
+        probe();  // the entry cell: no DDA step before it
+    };
     // One step of the walk for the calling lanes: DDA advance (core.rs:151-167), bounds (core.rs:129-134), bitmap probe.
     auto walk_step = [&]() __attribute__((always_inline)) {
-        const uint32_t n = mw & 1023u;
-        if (!(fl & F_FRESH)) RTF_DDA_ADVANCE();
-        fl &= ~F_FRESH;
-        if ((unsigned)ix < n && (unsigned)iy < n && (unsigned)iz < n) {
-            if (STATS) cnt.v[C_CELLS]++;
-            // (coordinates and n are below 2^10: 24-bit multiplies are full rate, 32-bit ones a quarter)
-            const uint32_t cell = ((mw >> 10) << 5) + __umul24(__umul24((uint32_t)iz, n) + (uint32_t)iy, n) + (uint32_t)ix;
-            uint32_t word;
-            // (ALL_LDS is a kernel parameter, not a branch: if the LDS probe and the HBM probe met in one block, the wait
-            // before the bit test would also wait for outstanding global loads.)  The bitmap of the arrival direction:
-            // cells whose entries were all tested one step ago count as empty; the counting build, and scenes whose seven
-            // bitmaps do not fit in LDS together (occ_dirs = 0: only the plain one is staged), use the plain occupancy.
-            const uint32_t wi = (A.occ_dirs ? (A.cull ? arr : 6u) : 0u) * occ_dir_words + (cell >> 5);
-            if (ALL_LDS) word = occ_lds[wi];
-            else word = occ_glb[wi];
-            if ((word >> (cell & 31u)) & 1u) {  // non-empty
-                // The cell's record is read by the next test phase, not here: a load into registers that an earlier
-                // step's load may still be filling makes the compiler wait for all of them.
-                k = cell;
-                fl |= F_WINIT | F_OPEN;
-            }
-        } else {  // left the grid without a hit
-            leave_model();
-        }
+        const bool ax_ = (tmx < tmy) && (tmx < tmz);
+        const bool ay_ = !(tmx < tmy) && (tmy < tmz);
+        const bool az_ = !ax_ && !ay_;
+        const double nx_ = tmx + tdx, ny_ = tmy + tdy, nz_ = tmz + tdz;
+        tmx = ax_ ? nx_ : tmx;
+        tmy = ay_ ? ny_ : tmy;
+        tmz = az_ ? nz_ : tmz;
+        // (selects of VALUES: a ?: between captured variables is lowered to a select of their addresses and sends them to the stack)
+        const uint32_t wx_ = wx, wy_ = wy, wz_ = wz;
+        const uint32_t wyz_ = ay_ ? wy_ : wz_;
+        const uint32_t w_ = ax_ ? wx_ : wyz_;
+        const uint32_t ryz_ = ay_ ? (1u << 10) : (1u << 20);
+        const uint32_t r_ = ax_ ? 1u : ryz_;
+        cv = (cv & ~7u) + w_;
+        rem -= r_;
+        if ((rem & kRemGuards) == kRemGuards) probe();
+        else leave_model();  // left the grid without a hit
     };
 
     for (;;) {
@@ -775,17 +785,16 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     tmx = I[at64(IT_DCOUNT, IT_TM + 0, it)]; tmy = I[at64(IT_DCOUNT, IT_TM + 1, it)]; tmz = I[at64(IT_DCOUNT, IT_TM + 2, it)];
                     tdx = I[at64(IT_DCOUNT, IT_TD + 0, it)]; tdy = I[at64(IT_DCOUNT, IT_TD + 1, it)]; tdz = I[at64(IT_DCOUNT, IT_TD + 2, it)];
                     const uint32_t cw = IU[at64(IU_COUNT, IU_CELL, it)];
-                    ix = (int)(cw & 1023u) - 1; iy = (int)((cw >> 10) & 1023u) - 1; iz = (int)((cw >> 20) & 1023u) - 1;
                     q = (uint32_t)it;
                     const uint32_t iw = IU[at64(IU_COUNT, IU_M, it)];
                     o = mk(Pst[at64(PF_COUNT, PF_O + 0, ps)], Pst[at64(PF_COUNT, PF_O + 1, ps)], Pst[at64(PF_COUNT, PF_O + 2, ps)]);
                     model_i = iw & 0xFFFFu;
-                    sgn = iw;
-                    mw = model_i < (uint32_t)kModelTab ? mtab[model_i] : (models_g[model_i].n | ((models_g[model_i].cell_base >> 5) << 10));
-                    fl = F_FRESH; arr = 6u;
+                    const uint32_t mw = model_i < (uint32_t)kModelTab ? mtab[model_i] : (models_g[model_i].n | ((models_g[model_i].cell_base >> 5) << 10));
                     bm = kNoId; btri = kNoId; bt = 0.0;
                     if (STATS) dg_ray_its = 0;
                     st = TS_TRAV;
+                    place((int)(cw & 1023u) - 1, (int)((cw >> 10) & 1023u) - 1, (int)((cw >> 20) & 1023u) - 1, (iw & IM_SX) != 0u,
+                          (iw & IM_SY) != 0u, (iw & IM_SZ) != 0u, mw & 1023u, mw >> 10);
                 }
                 const uint32_t want = (uint32_t)__popcll(idle);
                 pool_next += want < avail ? want : avail;
@@ -814,9 +823,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     } else {
                         const V3 P0 = ray_at(o, d, tmin);
                         const int n = (int)M.n;
-                        ix = cell_coord((P0.x - M.bmin[0]) / M.cell[0], n);
-                        iy = cell_coord((P0.y - M.bmin[1]) / M.cell[1], n);
-                        iz = cell_coord((P0.z - M.bmin[2]) / M.cell[2], n);
+                        const int ix = cell_coord((P0.x - M.bmin[0]) / M.cell[0], n);
+                        const int iy = cell_coord((P0.y - M.bmin[1]) / M.cell[1], n);
+                        const int iz = cell_coord((P0.z - M.bmin[2]) / M.cell[2], n);
                         const int sx = d.x > 0.0 ? 1 : -1, sy = d.y > 0.0 ? 1 : -1, sz = d.z > 0.0 ? 1 : -1;
                         const double nbx = (M.bmin[0] + M.hc2[0] * ((double)(ix + (sx > 0 ? 1 : 0)) + 0.5)) - M.hc[0];
                         const double nby = (M.bmin[1] + M.hc2[1] * ((double)(iy + (sy > 0 ? 1 : 0)) + 0.5)) - M.hc[1];
@@ -825,17 +834,15 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         tdx = ((double)sx * M.cell[0]) / d.x;
                         tdy = ((double)sy * M.cell[1]) / d.y;
                         tdz = ((double)sz * M.cell[2]) / d.z;
-                        sgn = (sx > 0 ? IM_SX : 0u) | (sy > 0 ? IM_SY : 0u) | (sz > 0 ? IM_SZ : 0u);
-                        mw = M.n | ((M.cell_base >> 5) << 10);
-                        fl = F_FRESH; arr = 6u;
                         st = TS_TRAV;
+                        place(ix, iy, iz, sx > 0, sy > 0, sz > 0, M.n, M.cell_base >> 5);
                     }
                 }
             }
             if (st == TS_ENTER) finish_ray();  // no model left
         }
         if (!__ballot(st == TS_TRAV)) continue;
-        // ---- traversal: all traversing lanes step together, whichever model each is in (what differs is `mw`)
+        // ---- traversal: all traversing lanes step together, whichever model each is in (what differs is per-lane state: cv, rem, wx, wy, wz)
         for (;;) {
             // A traversing lane is either WALKING (one DDA step and one bitmap probe per cell) or TESTING (its
             // cell's list is open); each iteration runs one of the two activities, whichever has the lanes.
@@ -865,17 +872,20 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 if (STATS) { dg_steps++; dg_step_lanes += nT; dg_wait_w += nW; dg_t0 = __builtin_amdgcn_s_memtime(); }
                 const bool testing = mine && (fl & F_OPEN);
                 if (STATS && testing) dg_ray_its += 1u << 16;
+                uint32_t frame_i = 0u;    // long cells: index of the cell's frame (word 2 of its record)
+                bool frame_known = false;
                 if (testing && (fl & F_WINIT)) {  // a newly opened cell: entries already tested in the cell the ray came from are skipped
                     // list range [k, k_end), k < k_end, and the arrival mask: one 32-byte record
-                    const gptr<uint32_t> ci = cell_info + (size_t)k * 8;
-                    const uint32_t mw = ci[2 + (arr < 6u ? arr : 0u)], w2 = ci[2];
+                    const gptr<uint32_t> ci = cell_info + (size_t)(cv >> 3) * 8;
+                    const uint32_t arr = cv & 7u;
+                    const uint32_t am = ci[2 + (arr < 6u ? arr : 0u)], w2 = ci[2];
                     k_end = ci[1];
                     k = ci[0];
                     const uint32_t len = k_end - k;
                     const uint32_t all = len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u);
-                    wmask = (A.cull && len <= 32u && arr < 6u) ? (all & mw) : all;
+                    wmask = (A.cull && len <= 32u && arr < 6u) ? (all & am) : all;
                     fl &= ~F_HI;
-                    if (len > 32u) { arr = 8u + w2; fl |= F_LONG; }  // a long cell: its frame index travels in `arr` (rewritten by the next DDA step)
+                    if (len > 32u) { frame_i = w2; frame_known = true; fl |= F_LONG; }  // a long cell
                     fl &= ~F_WINIT;
                 }
                 // Long cells: the window's entries are first tested against their 8-byte boxes (rtm_internal.h cell_box8) and
@@ -890,7 +900,8 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     uint32_t boff = 0u;
                     bool finite = false;
                     if (scan) {
-                        const gptr<double> F = cell_frame + (size_t)(arr - 8u) * 8;
+                        if (!frame_known) frame_i = cell_info[(size_t)(cv >> 3) * 8 + 2];  // a later window of a cell with more than 64 entries
+                        const gptr<double> F = cell_frame + (size_t)frame_i * 8;
                         const V3 ctr = ld3(F), iq = ld3(F + 3);
                         boff = (uint32_t)__double_as_longlong(F[6]);  // where the cell's boxes are, relative to its list positions
                         const V3 w = ctr - o;
@@ -1094,7 +1105,6 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             leave_model();
         }
     }
-#undef RTF_DDA_ADVANCE
     if (STATS) {  // longest ray of the wave (one atomic per wave, not per ray)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {

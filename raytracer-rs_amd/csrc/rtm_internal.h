@@ -44,8 +44,9 @@ struct RtmDevScene {
                                   // entries are NOT also listed in the neighbour cell a DDA step along -x,+x,-y,+y,-z,+z came from;
                                   // cells with more than 32 entries ("long cells") hold their frame index in word 2 instead
     const double* g_cell_rec;     // entries x 10, in list order: v0, v1-v0, v2-v0 of the entry's triangle, then its index in the model
-    const uint32_t* g_occ7;       // seven bitmaps of g_occ_dir_words words each: arrival directions -x,+x,-y,+y,-z,+z (bit = the cell has an
-                                  // entry that was not already tested in the neighbour the step came from), then the plain occupancy
+    const uint32_t* g_occ7;       // seven bitmaps, interleaved in groups of eight words per 32 cells (g_occ_dir_words groups): arrival directions
+                                  // -x,+x,-y,+y,-z,+z (bit = the cell has an entry that was not already tested in the neighbour the step
+                                  // came from), the plain occupancy, one spare word
     uint32_t g_occ_dir_words, g_reserved;
     const double* g_cell_frame;   // long cells x 8: centre xyz of the region that bounds the cell's triangles, quanta per unit length xyz,
                                   // (index of the cell's first box in g_cell_box8) - (list position of its first entry) as integer bits, 1 spare
