@@ -816,8 +816,16 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             A.ctr = (uint32_t*)(B + o_ctr);
             args_of[gi] = A;
         }
+#ifdef RTM_WAVE_TIMES
+        static unsigned long long* wt_buf = nullptr;  // diagnostics build: per-wave times of every trace launch of chunk 0
+        if (!wt_buf) HIP_TRY(hipMalloc((void**)&wt_buf, (size_t)64 * 8192 * 4 * 8));
+        HIP_TRY(hipMemsetAsync(wt_buf, 0, (size_t)64 * 8192 * 4 * 8, lanes[0]));
+#endif
         for (uint32_t r = 0; r < rounds; ++r) {
             for (uint32_t gi = 0; gi < n_group; ++gi) {
+#ifdef RTM_WAVE_TIMES
+                args_of[gi].dbg = (gi == 0 && chunk0 == 0 && r < 64) ? wt_buf + (size_t)r * 8192 * 4 : nullptr;
+#endif
                 const rtf::FrontArgs& A = args_of[gi];
                 hipStream_t stream = lanes[(chunk0 + gi) % n_conc];  // (shadows the caller's stream inside the loop)
                 mark(0, false, stream);
@@ -888,6 +896,16 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                 }
             }
         }
+#ifdef RTM_WAVE_TIMES
+        if (const char* path = std::getenv("RTM_WAVE_TIMES")) {  // written by the diagnostics build only
+            if (chunk0 == 0) {
+                std::vector<unsigned long long> h((size_t)64 * 8192 * 4);
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipMemcpy(h.data(), wt_buf, h.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+            }
+        }
+#endif
         for (uint32_t gi = 0; gi < n_group; ++gi) {
             const rtf::FrontArgs& A = args_of[gi];
             hipStream_t stream = lanes[(chunk0 + gi) % n_conc];

@@ -119,6 +119,9 @@ struct FrontArgs {
     uint32_t nq;                // sub-queues: wave w of the shade kernel reads live sub-list w % nq and appends to the same one
     uint32_t cap_l, cap_i;      // capacity of one live sub-list / one item sub-queue (cap_i = 3 * cap_l: a region of cap_l per query slot)
     uint32_t* ctr;              // [nq][CT_STRIDE]
+#ifdef RTM_WAVE_TIMES
+    unsigned long long* dbg;    // diagnostics build (tools/wave_times.py): [trace wave][4] = begin, queue exhausted, end (100 MHz ticks), rays taken
+#endif
 };
 
 RTM_DEV size_t at64(int n_fields, int f, size_t i) { return ((i >> 6) * (size_t)n_fields + (size_t)f) * 64u + (i & 63u); }
@@ -669,6 +672,10 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
     double bt = 0.0;  // closest model hit of this ray so far, over the models visited (core.rs:79-83)
     uint32_t bm = kNoId, btri = kNoId;
     bool exhausted = sq >= A.nq;
+#ifdef RTM_WAVE_TIMES
+    const unsigned long long wt_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wt_exh = 0, wt_rays = 0;
+#endif
     uint64_t dg_steps = 0, dg_step_lanes = 0, dg_walks = 0, dg_walk_lanes = 0, dg_slots = 0, dg_slot_lanes = 0, dg_refills = 0, dg_refill_lanes = 0;  // STATS only, wave-uniform
 
     uint64_t dg_idle = 0, dg_other = 0, dg_wait_t = 0, dg_wait_w = 0;  // STATS: lanes idle / in another state or model at a step; testers waiting in walk steps, walkers in test steps
@@ -776,6 +783,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                 }
                 const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 const uint32_t avail = pool_end - pool_next;
+#ifdef RTM_WAVE_TIMES
+                wt_rays += min((uint32_t)__popcll(idle), avail);
+#endif
                 if (st == TS_IDLE && rank < avail) {
                     const uint32_t li_ = pool_next + rank;  // position in the sub-queue -> region, position in the region
                     const uint32_t rg = (li_ >= sq_n0 ? 1u : 0u) + (li_ >= sq_n01 ? 1u : 0u);
@@ -802,6 +812,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             busy = __ballot(st != TS_IDLE);
             if (STATS) dg_tr += __builtin_amdgcn_s_memtime() - dg_t0;
         }
+#ifdef RTM_WAVE_TIMES
+        if (exhausted && !wt_exh) wt_exh = __builtin_amdgcn_s_memrealtime();
+#endif
         if (!busy) {
             if (exhausted) break;
             continue;
@@ -1105,6 +1118,12 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
             leave_model();
         }
     }
+#ifdef RTM_WAVE_TIMES
+    if (A.dbg && lane == 0) {
+        unsigned long long* const w = A.dbg + (size_t)wave_id * 4;
+        w[0] = wt_begin; w[1] = wt_exh; w[2] = __builtin_amdgcn_s_memrealtime(); w[3] = wt_rays;
+    }
+#endif
     if (STATS) {  // longest ray of the wave (one atomic per wave, not per ray)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
