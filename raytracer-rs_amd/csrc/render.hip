@@ -616,7 +616,7 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
         }
         V.g_occ_dir_words = (uint32_t)W;
         sd->occ7_words = (uint32_t)std::min<size_t>(W * 8, 0xFFFFFFFFu);
-        g_box8.resize(((g_box8.size() + 3) & ~(size_t)3) + 8, 0u);
+        g_box8.resize(((g_box8.size() + 3) & ~(size_t)3) + 2 * 64 + 8, 0u);  // (the screen reads a whole 64-entry pass from any cell's first box)
         if ((rc = upload(sd, occ7_all, &V.g_occ7)) || (rc = upload(sd, g_info, &V.g_cell_info)) || (rc = upload(sd, g_rec, &V.g_cell_rec)) ||
             (rc = upload(sd, g_frames, &V.g_cell_frame)) || (rc = upload(sd, g_box8, &V.g_cell_box8)))
             return fail(rc);

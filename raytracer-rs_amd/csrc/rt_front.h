@@ -932,31 +932,41 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     }
                     const float cx = -olx * ivx, cy = -oly * ivy, cz = -olz * ivz;
                     const uint32_t nwin = scan ? min(k_end - k, 64u) : 0u;  // the window and the 32 entries after it
-                    // the cell's boxes are packed from a 16-byte boundary (two entries per load); lanes that do not scan read entry 0
+                    // Which corner of a box the ray's line meets first is the same for every entry: the sign of the direction
+                    // picks the near and the far face per axis ONCE, as two byte selectors, and an entry's six coordinates are
+                    // put in (near x, near y, near z, far x | far y, far z) order by two byte permutes -- the slab test is then
+                    // max3 of the near times against min3 of the far ones, without a min and a max per axis and entry.
+                    // (iv is finite and t = x * iv + c is monotonic in x, so the near face's time IS min(t(x0), t(x1)).)
+                    const bool px_ = !(ivx < 0.f), py_ = !(ivy < 0.f), pz_ = !(ivz < 0.f);
+                    const uint32_t sel0 = (px_ ? 0u : 3u) | ((py_ ? 1u : 4u) << 8) | ((pz_ ? 2u : 5u) << 16) | ((px_ ? 3u : 0u) << 24);
+                    const uint32_t sel1 = (py_ ? 4u : 1u) | ((pz_ ? 5u : 2u) << 8) | 0x0C0C0000u;
+                    // the cell's boxes are packed from a 16-byte boundary (two entries per load) and the array is padded by a
+                    // window's length, so a pass reads 64 entries from the cell's first whatever the list's length (the bits of
+                    // entries beyond it are dropped below); lanes that do not scan read entry 0
                     const uint32_t bbase = scan ? k + boff : 0u;
                     uint32_t pass_h[2] = {0u, 0u};
                     typedef float v2f __attribute__((ext_vector_type(2)));
                     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                    const __attribute__((address_space(1))) u4* const box4 = (const __attribute__((address_space(1))) u4*)cell_box8;
+                    const __attribute__((address_space(1))) u4* const box4 = (const __attribute__((address_space(1))) u4*)cell_box8 + (bbase >> 1);
 #pragma unroll
                     for (uint32_t half = 0; half < 2u; ++half) {
                         uint32_t pass = 0u;
                         for (uint32_t j0 = half * 32u; j0 < half * 32u + 32u && __ballot(j0 < nwin); j0 += 8u) {
                             u4 bx[4];
 #pragma unroll
-                            for (uint32_t u = 0; u < 4u; ++u)  // (entries beyond the list read the list's last pair; their bits are dropped below)
-                                bx[u] = box4[(bbase + min(j0 + 2u * u, nwin ? (nwin - 1u) & ~1u : 0u)) >> 1];
+                            for (uint32_t u = 0; u < 4u; ++u) bx[u] = box4[(j0 >> 1) + u];
 #pragma unroll
                             for (uint32_t u = 0; u < 8u; ++u) {
                                 const uint32_t w0 = (u & 1u) ? bx[u >> 1].z : bx[u >> 1].x, w1 = (u & 1u) ? bx[u >> 1].w : bx[u >> 1].y;
-                                const float x0 = (float)(w0 & 255u), y0 = (float)((w0 >> 8) & 255u), z0 = (float)((w0 >> 16) & 255u);
-                                const float x1 = (float)(w0 >> 24), y1 = (float)(w1 & 255u), z1 = (float)((w1 >> 8) & 255u);
+                                const uint32_t q0 = __builtin_amdgcn_perm(w1, w0, sel0), q1 = __builtin_amdgcn_perm(w1, w0, sel1);
+                                const float nx = (float)(q0 & 255u), ny = (float)((q0 >> 8) & 255u), nz = (float)((q0 >> 16) & 255u);
+                                const float fx = (float)(q0 >> 24), fy = (float)(q1 & 255u), fz = (float)((q1 >> 8) & 255u);
                                 // (x - ol) * iv as one fused multiply-add with c = -ol * iv: its rounding moves a face by 1e-5 quantum
-                                const v2f tx = __builtin_elementwise_fma(v2f{x0, x1}, v2f{ivx, ivx}, v2f{cx, cx});
-                                const v2f ty = __builtin_elementwise_fma(v2f{y0, y1}, v2f{ivy, ivy}, v2f{cy, cy});
-                                const v2f tz = __builtin_elementwise_fma(v2f{z0, z1}, v2f{ivz, ivz}, v2f{cz, cz});
-                                const float tlo = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
-                                const float thi = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+                                const v2f tx = __builtin_elementwise_fma(v2f{nx, fx}, v2f{ivx, ivx}, v2f{cx, cx});
+                                const v2f ty = __builtin_elementwise_fma(v2f{ny, fy}, v2f{ivy, ivy}, v2f{cy, cy});
+                                const v2f tz = __builtin_elementwise_fma(v2f{nz, fz}, v2f{ivz, ivz}, v2f{cz, cz});
+                                const float tlo = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+                                const float thi = fminf(fminf(tx.y, ty.y), tz.y);
                                 pass |= (tlo > thi) ? 0u : (1u << ((j0 & 31u) + u));  // (a comparison with NaN is false: the entry stays)
                             }
                         }
