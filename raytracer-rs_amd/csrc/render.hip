@@ -37,6 +37,7 @@ static int g_device = -1;
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
+static uint32_t g_t_test_frac_long = 20;  // ... in scenes with long cells (every cell a ray meets is opened: test sooner); env RTM_TEST_FRAC_LONG
 static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); env RTM_KERNEL=wave|front
 #ifndef RTM_NOALLOC_SCRATCH_MIB
 #define RTM_NOALLOC_SCRATCH_MIB 256  // size of the static work space of rtm_render_device_noalloc
@@ -359,7 +360,8 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_CULL")) g_front_cull = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(64ll, std::atoll(e));
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("RTM_TEST_FRAC")) g_t_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_TEST_FRAC")) g_t_test_frac = g_t_test_frac_long = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_TEST_FRAC_LONG")) g_t_test_frac_long = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     return RTM_OK;
 }
@@ -800,7 +802,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
             A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
             A.cull = (stats && !(prof && prof->keep_cull) && !std::getenv("RTM_DIAG_KEEP_CULL")) ? 0u : g_front_cull;
-            A.refill = g_front_refill; A.t_test_frac = g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
+            A.refill = g_front_refill; A.t_test_frac = sd->n_long_cells ? g_t_test_frac_long : g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
             A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
             A.occ_words = occ_words;
             A.occ_plain = occ_plain_only ? 1u : 0u;

@@ -34,7 +34,10 @@ using namespace rtd;
 #define RTM_FWALK_UNROLL 4
 #endif
 #ifndef RTM_FTRI_WIDE
-#define RTM_FTRI_WIDE 4
+#define RTM_FTRI_WIDE 4  // list entries a lane tests per step
+#endif
+#ifndef RTM_FTRI_WIDE_LONG
+#define RTM_FTRI_WIDE_LONG 2  // ... in scenes with long cells: the box screen leaves two entries per cell on average (soup: 4 -> 2 slots, -7 %)
 #endif
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multiplied by 10 in 32 bits
@@ -926,9 +929,10 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         // (the screen is used only where f32 is good for 1e-2 quantum: frame origin within 2^16 quanta of the region)
                         finite = fabsf(olx) + fabsf(oly) + fabsf(olz) < 65536.0f && fabsf(dlx) + fabsf(dly) + fabsf(dlz) < __builtin_inff();
                         // 1 / direction, kept finite: a (near-)zero component makes its slab [-big, +big] or empty, as it should
-                        ivx = fabsf(dlx) >= 1e-30f ? 1.0f / dlx : __builtin_copysignf(1e30f, dlx);
-                        ivy = fabsf(dly) >= 1e-30f ? 1.0f / dly : __builtin_copysignf(1e30f, dly);
-                        ivz = fabsf(dlz) >= 1e-30f ? 1.0f / dlz : __builtin_copysignf(1e30f, dlz);
+                        // (the hardware's approximate reciprocal: one ulp of iv moves a face by 1e-5 quantum at most)
+                        ivx = fabsf(dlx) >= 1e-30f ? __builtin_amdgcn_rcpf(dlx) : __builtin_copysignf(1e30f, dlx);
+                        ivy = fabsf(dly) >= 1e-30f ? __builtin_amdgcn_rcpf(dly) : __builtin_copysignf(1e30f, dly);
+                        ivz = fabsf(dlz) >= 1e-30f ? __builtin_amdgcn_rcpf(dlz) : __builtin_copysignf(1e30f, dlz);
                     }
                     const float cx = -olx * ivx, cy = -oly * ivy, cz = -olz * ivz;
                     const uint32_t nwin = scan ? min(k_end - k, 64u) : 0u;  // the window and the 32 entries after it
@@ -950,8 +954,9 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const __attribute__((address_space(1))) u4* const box4 = (const __attribute__((address_space(1))) u4*)cell_box8 + (bbase >> 1);
 #pragma unroll
                     for (uint32_t half = 0; half < 2u; ++half) {
-                        uint32_t pass = 0u;
+                        uint32_t pass = 0u, n_done = 0u;  // entries of this half looked at (wave-uniform); their bits enter `pass` from below
                         for (uint32_t j0 = half * 32u; j0 < half * 32u + 32u && __ballot(j0 < nwin); j0 += 8u) {
+                            n_done += 8u;
                             u4 bx[4];
 #pragma unroll
                             for (uint32_t u = 0; u < 4u; ++u) bx[u] = box4[(j0 >> 1) + u];
@@ -967,10 +972,12 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                                 const v2f tz = __builtin_elementwise_fma(v2f{nz, fz}, v2f{ivz, ivz}, v2f{cz, cz});
                                 const float tlo = fmaxf(fmaxf(tx.x, ty.x), tz.x);
                                 const float thi = fminf(fminf(tx.y, ty.y), tz.y);
-                                pass |= (tlo > thi) ? 0u : (1u << ((j0 & 31u) + u));  // (a comparison with NaN is false: the entry stays)
+                                // pass = pass << 1 | !(tlo > thi), as a compare into the carry and one add-with-carry (a comparison
+                                // with NaN is false: the entry stays); the entries' bits arrive in reverse order
+                                asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(pass) : "v"(tlo), "v"(thi) : "vcc");
                             }
                         }
-                        pass_h[half] = pass;
+                        pass_h[half] = n_done ? __builtin_bitreverse32(pass) >> (32u - n_done) : 0u;
                     }
                     unsigned long long pass = ((unsigned long long)pass_h[1] << 32) | pass_h[0];
                     pass &= nwin >= 64u ? ~0ull : ((1ull << nwin) - 1ull);
@@ -1050,15 +1057,16 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     }
                 } else if (testing) {
                     bool have = (fl & F_HAVE) != 0u;
-                    // Up to RTM_FTRI_WIDE consecutive list entries, evaluated branch-free (model.rs:45-72): the
+                    // Up to kWide consecutive list entries, evaluated branch-free (model.rs:45-72): the
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
                     // the same side).  Entries are applied in list order (core.rs:140-142).
-                    uint32_t ti[RTM_FTRI_WIDE];
-                    double tt[RTM_FTRI_WIDE];
-                    bool ok[RTM_FTRI_WIDE];
+                    constexpr int kWide = HAS_LONG ? RTM_FTRI_WIDE_LONG : RTM_FTRI_WIDE;
+                    uint32_t ti[kWide];
+                    double tt[kWide];
+                    bool ok[kWide];
                     uint32_t cntw = 0;
 #pragma unroll
-                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) {  // the next untested entries, in list order
+                    for (int j = 0; j < kWide; ++j) {  // the next untested entries, in list order
                         const bool any = wmask != 0u;
                         const uint32_t b = any ? (uint32_t)__builtin_ctz(wmask) : 0u;
                         ti[j] = k + b;
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         cntw += any ? 1u : 0u;
                     }
 #pragma unroll
-                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) {
+                    for (int j = 0; j < kWide; ++j) {
                         tt[j] = 0.0;
                         ok[j] = false;
                         // slots beyond the second are evaluated only when some lane of the wave has that many
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                                 !(tt[j] < 0.0);
                     }
 #pragma unroll
-                    for (int j = 0; j < RTM_FTRI_WIDE; ++j) {
+                    for (int j = 0; j < kWide; ++j) {
                         const bool take = ok[j] && (!have || tt[j] < m_t);
                         m_t = take ? tt[j] : m_t;
                         m_tri = take ? ti[j] : m_tri;
