@@ -37,6 +37,7 @@ static int g_device = -1;
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
+static uint32_t g_front_wide = 0;  // test slots per step (0 = by scene); env RTM_FRONT_WIDE
 static uint32_t g_t_test_frac_long = 20;  // ... in scenes with long cells (every cell a ray meets is opened: test sooner); env RTM_TEST_FRAC_LONG
 static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); env RTM_KERNEL=wave|front
 #ifndef RTM_NOALLOC_SCRATCH_MIB
@@ -206,6 +207,7 @@ struct rtm_scene_dev {
     uint32_t max_n = 0;               // largest cells_per_side
     uint64_t max_list = 0;            // largest n_tri_idx
     uint64_t n_long_cells = 0;        // cells with more than 32 entries, over all models
+    uint64_t n_nonempty_cells = 0;    // cells with any entry, over all models
     uint32_t occ7_words = 0;          // words of the seven scene-wide bitmaps (rt_front.h)
     bool front_ok = true;             // the scene fits the packed indices of the ray-front path
     int device;
@@ -361,6 +363,7 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_MAX_PATHS")) g_front_max_paths = (size_t)std::max(64ll, std::atoll(e));
     if (const char* e = std::getenv("RTM_S_THRESHOLD")) g_s_threshold = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_TEST_FRAC")) g_t_test_frac = g_t_test_frac_long = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_FRONT_WIDE")) g_front_wide = (uint32_t)std::max(0, std::min(RTM_FTRI_WIDE, std::atoi(e)));
     if (const char* e = std::getenv("RTM_TEST_FRAC_LONG")) g_t_test_frac_long = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_T_MIN_LANES")) g_t_min_lanes = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     return RTM_OK;
@@ -593,6 +596,7 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
             for (size_t c = 0; c < n3; ++c) {
                 const uint32_t len = info[c * 8 + 1] - info[c * 8];
                 if (!len) continue;
+                sd->n_nonempty_cells++;
                 for (int a = 0; a < 6; ++a)
                     if (len > 32 || info[c * 8 + 2 + a] != 0u) occ7[(size_t)a * words + (c >> 5)] |= 1u << (c & 31);
                 occ7[6 * words + (c >> 5)] |= 1u << (c & 31);
@@ -802,7 +806,12 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
             A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
             A.cull = (stats && !(prof && prof->keep_cull) && !std::getenv("RTM_DIAG_KEEP_CULL")) ? 0u : g_front_cull;
-            A.refill = g_front_refill; A.t_test_frac = sd->n_long_cells ? g_t_test_frac_long : g_t_test_frac; A.t_min_lanes = g_t_min_lanes;
+            // Scenes where most non-empty cells are long (config 5's soup): the box screen leaves about two entries per cell and every
+            // cell a ray meets is opened, so two test slots per step and an earlier switch from walking to testing (soup -12 %);
+            // a scene with a few long cells (suzanne: lists up to 37) keeps the settings of short lists.
+            const bool dense = sd->n_long_cells * 2 >= sd->n_nonempty_cells && sd->n_long_cells > 0;
+            A.refill = g_front_refill; A.t_test_frac = dense ? g_t_test_frac_long : g_t_test_frac;
+            A.wide = g_front_wide ? g_front_wide : (dense ? 2u : (uint32_t)RTM_FTRI_WIDE); A.t_min_lanes = g_t_min_lanes;
             A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
             A.occ_words = occ_words;
             A.occ_plain = occ_plain_only ? 1u : 0u;

@@ -36,9 +36,7 @@ using namespace rtd;
 #ifndef RTM_FTRI_WIDE
 #define RTM_FTRI_WIDE 4  // list entries a lane tests per step
 #endif
-#ifndef RTM_FTRI_WIDE_LONG
-#define RTM_FTRI_WIDE_LONG 2  // ... in scenes with long cells: the box screen leaves two entries per cell on average (soup: 4 -> 2 slots, -7 %)
-#endif
+
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multiplied by 10 in 32 bits
 constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256, kShadeSpheres = 256, kShadePlanes = 64;  // table sizes the shade kernel keeps in LDS
@@ -109,6 +107,7 @@ struct FrontArgs {
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
     uint32_t coop;              // trace kernel: 1 = when at most four rays of a wave are testing, the other lanes test their entries
     uint32_t t_test_frac, t_min_lanes;
+    uint32_t wide;              // trace kernel: list entries a lane tests per step (at most RTM_FTRI_WIDE)
     uint32_t occ_words;         // bitmap words the trace kernel stages in LDS: all of g_occ7 (occ_plain = 0) or its plain occupancy alone
     uint32_t occ_plain;         // 1: only the plain occupancy (slot 6 of every group of eight words) is staged, one word per 32 cells
     uint32_t occ_shift, occ_m1, occ_m2;  // bitmap word of cell c arriving from direction a: ((c >> 5) << occ_shift) + ((a & occ_m1) | occ_m2)
@@ -1060,17 +1059,17 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     // Up to kWide consecutive list entries, evaluated branch-free (model.rs:45-72): the
                     // reference's early returns become one predicate built from the same comparisons (so NaNs take
                     // the same side).  Entries are applied in list order (core.rs:140-142).
-                    constexpr int kWide = HAS_LONG ? RTM_FTRI_WIDE_LONG : RTM_FTRI_WIDE;
+                    constexpr int kWide = RTM_FTRI_WIDE;
                     uint32_t ti[kWide];
                     double tt[kWide];
                     bool ok[kWide];
                     uint32_t cntw = 0;
 #pragma unroll
                     for (int j = 0; j < kWide; ++j) {  // the next untested entries, in list order
-                        const bool any = wmask != 0u;
+                        const bool any = wmask != 0u && (uint32_t)j < A.wide;  // (A.wide slots per step: see render.hip)
                         const uint32_t b = any ? (uint32_t)__builtin_ctz(wmask) : 0u;
                         ti[j] = k + b;
-                        wmask &= wmask - 1u;
+                        wmask = any ? (wmask & (wmask - 1u)) : wmask;
                         cntw += any ? 1u : 0u;
                     }
 #pragma unroll
