@@ -744,6 +744,13 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t n_conc = fixed ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({g_front_streams, (uint32_t)kFrontStreamsMax, bands_total}));
     uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / n_conc / band_paths);
     bands_per_chunk = std::min(bands_per_chunk, (bands_total + n_conc - 1) / n_conc);
+    {   // (pixel of the tile, tile column, tile row of the chunk, sample) of a path travel packed in one word (rt_front.h PU_HOME):
+        // width x spp is bounded by front_supported(), the rows of a chunk are bounded here
+        auto bits = [](uint32_t n) { uint32_t b = 1; while ((1u << b) < n) ++b; return b; };
+        const uint32_t used = 6u + bits(tiles_x) + bits(p->spp);
+        if (used > 31u) return rtm_internal_fail(RTM_ERR_INVALID, "width x spp too large for one band of paths");
+        bands_per_chunk = std::min(bands_per_chunk, 1u << std::min(20u, 32u - used - 1u));
+    }
     // sub-queues (rt_front.h): the shade grid has exactly nq waves, one sub-list per shade wave.  (The fixed work space
     // uses a third of them: every sub-queue owns whole 64-path blocks, which is what a small work space is spent on.)
     const uint32_t nq = (uint32_t)g_num_cus * (fixed ? 8u : g_front_shade_waves_per_cu);
@@ -823,6 +830,11 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             A.D[0] = (double*)(B + o_D0); A.D[1] = (double*)(B + o_D1); A.U[0] = (uint32_t*)(B + o_U0); A.U[1] = (uint32_t*)(B + o_U1);
             A.fin = (double*)(B + o_fin); A.res = (rtf::FrontResult*)(B + o_res);
             A.itD = (double*)(B + o_itD); A.itU = (uint32_t*)(B + o_itU);
+            {   // PU_HOME's fields (rt_front.h): 6 bits pixel of the tile, then tile column, tile row of the chunk, sample
+                auto bits = [](uint32_t n) { uint32_t b = 1; while ((1u << b) < n) ++b; return b; };
+                const uint32_t bx = bits(tiles_x), by = bits(bands_per_chunk);
+                A.home_sy = 6u + bx; A.home_ss = 6u + bx + by; A.home_mx = (1u << bx) - 1u; A.home_my = (1u << by) - 1u;
+            }
             A.nq = nq; A.cap_l = ((((A.np + 63u) / 64u) + nq - 1) / nq) * 64u; A.cap_i = A.cap_l * 3u; A.cap_items = nq * A.cap_i;
             A.ctr = (uint32_t*)(B + o_ctr);
             args_of[gi] = A;

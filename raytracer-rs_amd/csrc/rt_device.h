@@ -68,8 +68,10 @@ RTM_DEV void philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), c3 = 0u;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // (one 32 x 32 -> 64 multiply per product: written as a high and a low half it becomes two quarter-rate instructions)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+        const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;

@@ -113,7 +113,8 @@ struct FrontArgs {
     uint32_t occ_shift, occ_m1, occ_m2;  // bitmap word of cell c arriving from direction a: ((c >> 5) << occ_shift) + ((a & occ_m1) | occ_m2)
     double* D[2];               // path state, streamed from one buffer to the other every round
     uint32_t* U[2];
-    double* fin;                // [at64(3, c, home slot)]: colour of a finished sample
+    double* fin;                // [at64(3, c, (sample * n_tiles + tile) * 64 + pixel of the tile)]: colour of a finished sample
+    uint32_t home_sy, home_ss, home_mx, home_my;  // PU_HOME = pixel of the tile | tile column << 6 | tile row << home_sy | sample << home_ss
     FrontResult* res;           // [item index]: what the trace kernel found for the query of that item
     double* itD;
     uint32_t* itU;
@@ -228,12 +229,24 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         auto ldD3 = [&](int f) -> V3 { return mk(ldD(f), ldD(f + 1), ldD(f + 2)); };
         auto ldU = [&](int f) -> uint32_t { return Uin[at64(PU_COUNT, f, p)]; };
 
-        // home slot -> sample, pixel (the slot the path had in round 0; block b lives at (b % nq) * cap_l + (b / nq) * 64)
-        const uint32_t home = (ROUND0 || !valid) ? p : ldU(PU_HOME);
-        const uint32_t blk = ((home % A.cap_l) >> 6) * A.nq + home / A.cap_l;
-        const uint32_t s = blk / A.n_tiles, tile = blk - s * A.n_tiles, in = home & 63u;
-        const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
-        const uint32_t lyc = (tile / A.tiles_x) * 8u + (in >> 3);
+        // which sample of which pixel the path is: packed into one word in round 0 (the wave's k-th block is block
+        // k * nq + sq = (sample, tile): divisions of wave-uniform numbers) and carried along -- later rounds unpack it
+        // with shifts instead of dividing by the tile counts for every path
+        uint32_t home, s, tile_x, tile_y;
+        if (ROUND0) {
+            const uint32_t blk = k * A.nq + sq;
+            s = blk / A.n_tiles;
+            const uint32_t tile = blk - s * A.n_tiles;
+            tile_y = tile / A.tiles_x;
+            tile_x = tile - tile_y * A.tiles_x;
+            home = lane | (tile_x << 6) | (tile_y << A.home_sy) | (s << A.home_ss);
+        } else {
+            home = valid ? ldU(PU_HOME) : 0u;
+            tile_x = (home >> 6) & A.home_mx; tile_y = (home >> A.home_sy) & A.home_my; s = home >> A.home_ss;
+        }
+        const uint32_t in = home & 63u;
+        const uint32_t x = tile_x * 8u + (in & 7u);
+        const uint32_t lyc = tile_y * 8u + (in >> 3);
         if (ROUND0 && !(x < A.W && lyc < A.rows)) valid = false;  // padding of a ragged tile: never alive
         const uint32_t ly = A.row0 + lyc;
         const uint32_t yy = A.row_begin + ly * A.row_stride;
@@ -385,7 +398,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 }
                 if (b_miss) col = col + mk(1, 1, 1) * att;  // main.rs:127
                 if (end_sample) {  // the sample's colour, where the resolve kernel looks for it
-                    A.fin[at64(3, 0, home)] = col.x; A.fin[at64(3, 1, home)] = col.y; A.fin[at64(3, 2, home)] = col.z;
+                    const size_t fi = (size_t)((s * A.n_tiles + tile_y * A.tiles_x + tile_x) * 64u + in);
+                    A.fin[at64(3, 0, fi)] = col.x; A.fin[at64(3, 1, fi)] = col.y; A.fin[at64(3, 2, fi)] = col.z;
                 }
                 bool norm0 = false;
                 if (b_hit) {
@@ -1184,8 +1198,7 @@ __global__ __launch_bounds__(kBlock) void front_resolve_kernel(FrontArgs A, doub
     const double n_spp = (double)A.spp;
     V3 px = mk(0, 0, 0);
     for (uint32_t s = 0; s < A.spp; ++s) {
-        const uint32_t blk = s * A.n_tiles + tile;
-        const size_t p = (size_t)(blk % A.nq) * A.cap_l + (size_t)(blk / A.nq) * 64u + in;  // the slot the shade kernel used
+        const size_t p = (size_t)(s * A.n_tiles + tile) * 64u + in;  // where the shade kernel put the sample's colour
         px = px + mk(A.fin[at64(3, 0, p)], A.fin[at64(3, 1, p)], A.fin[at64(3, 2, p)]) / n_spp;
     }
     const size_t oi = (size_t)(A.row0 + lyc) * A.W + x;
