@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--no-isolated", action="store_true",
                     help="skip the extra pass with one chunk in flight (rocprofv3 runs: every launch of the process is then in the "
                          "regime of the timed steps, and the profiler's average kernel duration is comparable with roofline.kernel_ms)")
-    ap.add_argument("--streams", type=int, default=2, help="chunks of a frame in flight at once (rtm_set_tuning front_streams; default 2)")
+    ap.add_argument("--streams", type=int, default=0, help="chunks of a frame in flight at once (rtm_set_tuning front_streams; default 0 = the library's choice by frame size)")
     ap.add_argument("--gather", choices=("f64", "u8"), default="f64",
                     help="N > 1: what rank 0 collects -- the f64 framebuffer (default, the parity path) or the 8-bit image "
                          "after the device tonemap (main.rs:173-185; an eighth of the bytes)")

@@ -44,7 +44,7 @@ static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); 
 #define RTM_NOALLOC_SCRATCH_MIB 256  // size of the static work space of rtm_render_device_noalloc
 #endif
 constexpr int kFrontStreamsMax = 4;
-static uint32_t g_front_streams = 2;  // chunks of a frame in flight at once; env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
+static uint32_t g_front_streams = 0;  // chunks of a frame in flight at once (0 = by frame size: 3 from 12 Mi sample paths, else 2); env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
 static hipStream_t g_front_stream[kFrontStreamsMax] = {};
 static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
 static bool g_front_trace_wgs_env = false;
@@ -349,7 +349,7 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_STEAL")) g_front_steal = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
     g_front_debug_rounds = std::getenv("RTM_FRONT_DEBUG_ROUNDS") != nullptr;
-    if (const char* e = std::getenv("RTM_FRONT_STREAMS")) g_front_streams = (uint32_t)std::max(1, std::min(kFrontStreamsMax, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_FRONT_STREAMS")) g_front_streams = (uint32_t)std::max(0, std::min(kFrontStreamsMax, std::atoi(e)));
     if (!g_front_fork) {
         HIP_TRY(hipEventCreateWithFlags(&g_front_fork, hipEventDisableTiming));
         for (int i = 0; i < kFrontStreamsMax; ++i) {
@@ -379,7 +379,7 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
     if (k == "front_timed_events" && (value == 0 || value == 1)) { g_front_timed_events = value != 0; return RTM_OK; }
     if (k == "front_steal" && value >= 0 && value <= 4096) { g_front_steal = (uint32_t)value; return RTM_OK; }
-    if (k == "front_streams" && value >= 1 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
+    if (k == "front_streams" && value >= 0 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
     return rtm_internal_fail(RTM_ERR_INVALID, "unknown tuning key or value out of range: " + k);
 }
 
@@ -741,7 +741,9 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t bands_total = (n_rows + 7) / 8;
     // The frame is cut into chunks of whole 8-row bands; chunk c runs on internal stream c % n_conc with its own work space,
     // so the late rounds of one chunk (few paths alive: launch- and latency-bound) overlap the heavy rounds of another.
-    const uint32_t n_conc = fixed ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({g_front_streams, (uint32_t)kFrontStreamsMax, bands_total}));
+    // (measured on rank shares of the bunny frame: three chunks in flight win from about 12 Mi paths, two below, `profiles/`)
+    const uint32_t want_conc = g_front_streams ? g_front_streams : (band_paths * bands_total >= ((size_t)12 << 20) ? 3u : 2u);
+    const uint32_t n_conc = fixed ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({want_conc, (uint32_t)kFrontStreamsMax, bands_total}));
     uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / n_conc / band_paths);
     bands_per_chunk = std::min(bands_per_chunk, (bands_total + n_conc - 1) / n_conc);
     {   // (pixel of the tile, tile column, tile row of the chunk, sample) of a path travel packed in one word (rt_front.h PU_HOME):
