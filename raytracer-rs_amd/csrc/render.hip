@@ -853,6 +853,12 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
 #endif
                 const rtf::FrontArgs& A = args_of[gi];
                 hipStream_t stream = lanes[(chunk0 + gi) % n_conc];  // (shadows the caller's stream inside the loop)
+                unsigned long long* shade_cnt = d_cnt;
+#ifdef RTM_SHADE_TIMES
+                static unsigned long long* st_buf = nullptr;  // diagnostics build: cycles per phase of the shade kernel's iterations
+                if (!st_buf) { HIP_TRY(hipMalloc((void**)&st_buf, 40 * 8)); }
+                if (!d_cnt) { HIP_TRY(hipMemsetAsync(st_buf, 0, 40 * 8, stream)); shade_cnt = st_buf; }
+#endif
                 mark(0, false, stream);
                 {
                     const bool tabs = sd->view.n_lights <= (uint32_t)rtf::kShadeLights && sd->view.n_materials <= (uint32_t)rtf::kShadeMats &&
@@ -861,7 +867,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     const size_t slds = tabs ? rtf::kShadeLdsBytes : 0;
                     switch ((stats ? 4 : 0) | (r == 0 ? 2 : 0) | (tabs ? 1 : 0)) {
 #define RTM_SHADE_CASE(v, S_, R_, T_) \
-    case v: hipLaunchKernelGGL((rtf::front_shade_kernel<S_, R_, T_>), dim3(shade_wgs0), block, slds, stream, sd->view, A, r, d_obj, d_tri, d_cnt); break;
+    case v: hipLaunchKernelGGL((rtf::front_shade_kernel<S_, R_, T_>), dim3(shade_wgs0), block, slds, stream, sd->view, A, r, d_obj, d_tri, shade_cnt); break;
                         RTM_SHADE_CASE(0, false, false, false) RTM_SHADE_CASE(1, false, false, true)
                         RTM_SHADE_CASE(2, false, true, false) RTM_SHADE_CASE(3, false, true, true)
                         RTM_SHADE_CASE(4, true, false, false) RTM_SHADE_CASE(5, true, false, true)
@@ -870,6 +876,16 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     }
                 }
                 mark(0, true, stream);
+#ifdef RTM_SHADE_TIMES
+                if (!d_cnt && gi == 0 && std::getenv("RTM_SHADE_TIMES")) {
+                    unsigned long long h5[5];
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    HIP_TRY(hipMemcpy(h5, st_buf + 34, sizeof h5, hipMemcpyDeviceToHost));
+                    if (h5[4])
+                        std::fprintf(stderr, "[rtm shade times] round %u: %llu wave iterations; cycles per iteration: state loads %.0f, answers %.0f, compute %.0f, stores %.0f\n",
+                                     r, h5[4], (double)h5[0] / h5[4], (double)h5[1] / h5[4], (double)h5[2] / h5[4], (double)h5[3] / h5[4]);
+                }
+#endif
                 if (prof && prof->d_items && !prof->keep_cull)
                     hipLaunchKernelGGL(front_sum_items_kernel, dim3(32), dim3(256), 0, stream, A.ctr, nq, prof->d_items);
                 if (r + 1 < rounds) {  // the last round only finalises

@@ -218,7 +218,13 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
     // The flag word of a path is read one iteration ahead: which of the previous round's answers exist (and so where
     // they are) is known when the iteration's loads are issued, instead of one memory latency later.
     uint32_t flb_next = (!ROUND0 && lane < n_in_list) ? Uin[at64(PU_COUNT, PU_FLB, (size_t)sq * A.cap_l + lane)] : 0u;
+#ifdef RTM_SHADE_TIMES
+    unsigned long long st_t[5] = {0, 0, 0, 0, 0};  // diagnostics build: cycles waiting for the loads / answers, computing, storing; iterations
+#endif
     for (uint32_t k = 0; k * 64u < n_in_list; ++k) {  // wave-uniform trip count
+#ifdef RTM_SHADE_TIMES
+        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t idx = k * 64u + lane;
         bool valid = idx < n_in_list;
         const uint32_t p = sq * A.cap_l + (valid ? idx : 0u);  // slot read this round
@@ -296,6 +302,10 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 if (nL > 2u) diff = ldD3(PF_DIFF);
             }
         }
+#ifdef RTM_SHADE_TIMES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+#endif
         // ---- the answers of the previous round: the next entry of region j for every path whose flag says it asked
         //      (a held answer of slot 0 was read in the round after its ray was traced; its flag stays set)
         FrontResult r0, l_r1, l_r2;
@@ -310,6 +320,10 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
             if (q2) l_r2 = A.res[rbase + 2u * A.cap_l + n_res2 + (uint32_t)__popcll(m2 & below)];
             n_res0 += (uint32_t)__popcll(m0); n_res1 += (uint32_t)__popcll(m1); n_res2 += (uint32_t)__popcll(m2);
         }
+#ifdef RTM_SHADE_TIMES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+#endif
         if (valid) {
             if (!ROUND0) {
                 if (fl & FB_HELD) { r0.t = held_t; r0.tri = held_tri; r0.model = held_m; }  // slot 0's answer came in an earlier round
@@ -591,6 +605,9 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
             shadow(0u, go1);
             shadow(1u, go2);
         }
+#ifdef RTM_SHADE_TIMES
+        const unsigned long long st_d = __builtin_amdgcn_s_memtime();
+#endif
         if (valid && cont) {  // the state moves on
             stD3(PF_COL, col); stD(PF_ATT, att);
             stD3(PF_O, o); stD3(PF_D0, dir0);
@@ -600,7 +617,17 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
             stU(PU_HKP, h_kp); stU(PU_MAT, mat);
             stU(PU_HOME, home);
         }
+#ifdef RTM_SHADE_TIMES
+        {
+            const unsigned long long st_e = __builtin_amdgcn_s_memtime();
+            st_t[0] += st_b - st_a; st_t[1] += st_c - st_b; st_t[2] += st_d - st_c; st_t[3] += st_e - st_d; st_t[4] += 1;
+        }
+#endif
     }
+#ifdef RTM_SHADE_TIMES
+    if (lane == 0 && out_cnt)
+        for (int i = 0; i < 5; ++i) atomicAdd(out_cnt + 34 + i, st_t[i]);
+#endif
     if (lane == 0) {
         my_ctr[(round + 1u) & 1u] = n_live_local;
         my_ctr[CT_ITEMS0] = n_items0; my_ctr[CT_ITEMS0 + 1] = n_items1; my_ctr[CT_ITEMS0 + 2] = n_items2;
