@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--no-isolated", action="store_true",
                     help="skip the extra pass with one chunk in flight (rocprofv3 runs: every launch of the process is then in the "
                          "regime of the timed steps, and the profiler's average kernel duration is comparable with roofline.kernel_ms)")
-    ap.add_argument("--streams", type=int, default=0, help="chunks of a frame in flight at once (rtm_set_tuning front_streams; default 0 = the library's choice by frame size)")
+    ap.add_argument("--streams", type=int, default=2, help="chunks of a frame in flight at once (rtm_set_tuning front_streams; default 2, 0 = by frame size)")
     ap.add_argument("--gather", choices=("f64", "u8"), default="f64",
                     help="N > 1: what rank 0 collects -- the f64 framebuffer (default, the parity path) or the 8-bit image "
                          "after the device tonemap (main.rs:173-185; an eighth of the bytes)")
@@ -269,7 +269,7 @@ def main():
                                     "the oracle's). The device path answers shadow rays whose light is behind the surface (main.rs:96 "
                                     "fails) without tracing them: rays_issued is what it does issue, and of those only the rays that "
                                     "enter a model's box reach the trace kernel: rays_traced (both on this rank)",
-                       "front_streams": args.streams, "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if world > 1 else "")},
+                       "front_streams": args.streams or "by frame size (3 chunks in flight from 12 Mi sample paths per frame, else 2)", "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>" if single else
                          ("rtf::front_trace_kernel<false, true, true>" if args.workload == "soup" else "rtf::front_trace_kernel<false, true, false>"),

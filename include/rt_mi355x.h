@@ -127,8 +127,8 @@ const char* rtm_version(void);
  *   "front_max_paths"  sample paths kept in flight per band of rows (workspace: ~700 B each; default 32 Mi),
  *   "front_cull"       1 (default): shadow rays whose light is behind the surface (main.rs:96 fails) are not traced,
  *   "front_refill"     idle lanes per wave at which the trace kernel fetches new rays (default 24),
- *   "front_streams"    chunks of a frame in flight at once on internal streams (1..4; default 0 = by frame size: 3 from 12 Mi
- *                      sample paths per frame, else 2),
+ *   "front_streams"    chunks of a frame in flight at once on internal streams (1..4, default 2; 0 = by frame size: 3 from
+ *                      12 Mi sample paths per frame, else 2),
  *   "front_claim"      ray items a trace wave claims from a sub-queue at a time (>= 16, default 128),
  *   "front_steal"      sub-queues of other waves a trace wave may try when its own are empty (default 8),
  *   "front_timed_events"  1: event pairs around the trace launches of ordinary frames (rtm_timed_events_collect),

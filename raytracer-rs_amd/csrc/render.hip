@@ -44,7 +44,7 @@ static int g_kernel = 2;              // 0: rt_wave.h, 2: rt_front.h (default); 
 #define RTM_NOALLOC_SCRATCH_MIB 256  // size of the static work space of rtm_render_device_noalloc
 #endif
 constexpr int kFrontStreamsMax = 4;
-static uint32_t g_front_streams = 0;  // chunks of a frame in flight at once (0 = by frame size: 3 from 12 Mi sample paths, else 2); env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
+static uint32_t g_front_streams = 2;  // chunks of a frame in flight at once (0 = by frame size: 3 from 12 Mi sample paths, else 2); env RTM_FRONT_STREAMS / rtm_set_tuning("front_streams")
 static hipStream_t g_front_stream[kFrontStreamsMax] = {};
 static hipEvent_t g_front_fork = nullptr, g_front_join[kFrontStreamsMax] = {};
 static bool g_front_trace_wgs_env = false;
@@ -741,7 +741,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t bands_total = (n_rows + 7) / 8;
     // The frame is cut into chunks of whole 8-row bands; chunk c runs on internal stream c % n_conc with its own work space,
     // so the late rounds of one chunk (few paths alive: launch- and latency-bound) overlap the heavy rounds of another.
-    // (measured on rank shares of the bunny frame: three chunks in flight win from about 12 Mi paths, two below, `profiles/`)
+    // (0: three chunks in flight win 1-2 % on the whole bunny frame and lose 4 % on suzanne and on small rank shares: not the default)
     const uint32_t want_conc = g_front_streams ? g_front_streams : (band_paths * bands_total >= ((size_t)12 << 20) ? 3u : 2u);
     const uint32_t n_conc = fixed ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({want_conc, (uint32_t)kFrontStreamsMax, bands_total}));
     uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / n_conc / band_paths);

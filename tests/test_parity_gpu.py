@@ -111,7 +111,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
     ref = oracle_scene("suzanne").render(spp=3, seed=4, width=203, height=77)
     try:
         for key, value in (("front_max_paths", 64), ("front_max_paths", 26 * 64 * 3 * 4), ("front_cull", 0), ("front_refill", 1),
-                           ("front_refill", 64), ("front_streams", 1), ("front_streams", 4), ("front_claim", 16), ("front_steal", 512),
+                           ("front_refill", 64), ("front_streams", 1), ("front_streams", 4), ("front_streams", 0), ("front_claim", 16), ("front_steal", 512),
                            ("front_steal", 0), ("front_coop", 0)):
             rtm_gpu.set_tuning(key, value)
             g = s.render(spp=3, seed=4, width=203, height=77, stats=True)
@@ -123,7 +123,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("front_max_paths", 32 << 20)
         rtm_gpu.set_tuning("front_cull", 1)
         rtm_gpu.set_tuning("front_refill", 24)
-        rtm_gpu.set_tuning("front_streams", 0)
+        rtm_gpu.set_tuning("front_streams", 2)
         rtm_gpu.set_tuning("front_claim", 128)
         rtm_gpu.set_tuning("front_steal", 8)
         rtm_gpu.set_tuning("front_coop", 1)
@@ -255,7 +255,7 @@ def test_two_caller_streams_do_not_corrupt_each_other(rtm_gpu, rtm_scene):
                 assert np.array_equal(a[i].cpu().numpy(), ref_a), f"streams={streams} frame a{i}"
                 assert np.array_equal(b[i].cpu().numpy(), ref_b), f"streams={streams} frame b{i}"
     finally:
-        rtm_gpu.set_tuning("front_streams", 0)
+        rtm_gpu.set_tuning("front_streams", 2)
 
 
 def test_edge_cases(rtm_gpu, orc):
