@@ -78,8 +78,10 @@ enum : uint32_t {
 };
 constexpr uint32_t kMaxFrontBounces = 0xFFFFu;
 // trace items, structure of arrays over the item index.  The origin is not in the item: all queries of a path start at
-// PF_O of the state the shade kernel has just written, and the item names that slot.
-enum : int { IT_D = 0, IT_TM = 3, IT_TD = 6, IT_DCOUNT = 9 };
+// PF_O of the state the shade kernel has just written, and the item names that slot; the direction of a path query
+// (region 0) is that state's PF_D0, only shadow queries bring theirs; tDelta (core.rs:119-125) is three divisions of
+// numbers the trace kernel has, made where the item is read rather than carried through memory.
+enum : int { IT_TM = 0, IT_D = 3, IT_DCOUNT = 6 };
 enum : int { IU_CELL = 0, IU_P = 1, IU_M = 2, IU_COUNT = 3 };
 enum : uint32_t { IM_SX = 1u << 16, IM_SY = 1u << 17, IM_SZ = 1u << 18 };
 // device counters, one set per sub-queue (each written by the one wave that owns the sub-queue)
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         auto issue = [&](const uint32_t j, const bool go, const V3 dir, const double dl2, const bool lit) __attribute__((always_inline)) {
             bool item = false;
             int ix = 0, iy = 0, iz = 0;
-            double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
+            double tmx = 0, tmy = 0, tmz = 0;
             uint32_t mword = 0;
             if (go) {
                 double best = __builtin_inf();
@@ -555,9 +557,6 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                             const double nby = (M.bmin[1] + M.hc2[1] * ((double)(iy + (sy > 0 ? 1 : 0)) + 0.5)) - M.hc[1];
                             const double nbz = (M.bmin[2] + M.hc2[2] * ((double)(iz + (sz > 0 ? 1 : 0)) + 0.5)) - M.hc[2];
                             tmx = (nbx - P0.x) / dir.x; tmy = (nby - P0.y) / dir.y; tmz = (nbz - P0.z) / dir.z;
-                            tdx = ((double)sx * M.cell[0]) / dir.x;
-                            tdy = ((double)sy * M.cell[1]) / dir.y;
-                            tdz = ((double)sz * M.cell[2]) / dir.z;
                             mword = m | (sx > 0 ? IM_SX : 0u) | (sy > 0 ? IM_SY : 0u) | (sz > 0 ? IM_SZ : 0u);
                             item = true;
                         }
@@ -574,9 +573,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 if (item) {
                     const size_t it = (size_t)sq * A.cap_i + at + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
                     double* const I = A.itD;
-                    I[at64(IT_DCOUNT, IT_D + 0, it)] = dir.x; I[at64(IT_DCOUNT, IT_D + 1, it)] = dir.y; I[at64(IT_DCOUNT, IT_D + 2, it)] = dir.z;
+                    if (j != 0u) { I[at64(IT_DCOUNT, IT_D + 0, it)] = dir.x; I[at64(IT_DCOUNT, IT_D + 1, it)] = dir.y; I[at64(IT_DCOUNT, IT_D + 2, it)] = dir.z; }
                     I[at64(IT_DCOUNT, IT_TM + 0, it)] = tmx; I[at64(IT_DCOUNT, IT_TM + 1, it)] = tmy; I[at64(IT_DCOUNT, IT_TM + 2, it)] = tmz;
-                    I[at64(IT_DCOUNT, IT_TD + 0, it)] = tdx; I[at64(IT_DCOUNT, IT_TD + 1, it)] = tdy; I[at64(IT_DCOUNT, IT_TD + 2, it)] = tdz;
                     A.itU[at64(IU_COUNT, IU_CELL, it)] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
                     A.itU[at64(IU_COUNT, IU_P, it)] = p_out;  // the path's next slot: where the trace kernel finds the ray's origin
                     A.itU[at64(IU_COUNT, IU_M, it)] = mword;
@@ -834,14 +832,21 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const uint32_t rg = (li_ >= sq_n0 ? 1u : 0u) + (li_ >= sq_n01 ? 1u : 0u);
                     const size_t it = (size_t)sq * A.cap_i + (size_t)rg * A.cap_l + (li_ - (rg == 0u ? 0u : (rg == 1u ? sq_n0 : sq_n01)));
                     const size_t ps = IU[at64(IU_COUNT, IU_P, it)];
-                    d = mk(I[at64(IT_DCOUNT, IT_D + 0, it)], I[at64(IT_DCOUNT, IT_D + 1, it)], I[at64(IT_DCOUNT, IT_D + 2, it)]);
+                    if (rg == 0u) d = mk(Pst[at64(PF_COUNT, PF_D0 + 0, ps)], Pst[at64(PF_COUNT, PF_D0 + 1, ps)], Pst[at64(PF_COUNT, PF_D0 + 2, ps)]);
+                    else d = mk(I[at64(IT_DCOUNT, IT_D + 0, it)], I[at64(IT_DCOUNT, IT_D + 1, it)], I[at64(IT_DCOUNT, IT_D + 2, it)]);
                     tmx = I[at64(IT_DCOUNT, IT_TM + 0, it)]; tmy = I[at64(IT_DCOUNT, IT_TM + 1, it)]; tmz = I[at64(IT_DCOUNT, IT_TM + 2, it)];
-                    tdx = I[at64(IT_DCOUNT, IT_TD + 0, it)]; tdy = I[at64(IT_DCOUNT, IT_TD + 1, it)]; tdz = I[at64(IT_DCOUNT, IT_TD + 2, it)];
                     const uint32_t cw = IU[at64(IU_COUNT, IU_CELL, it)];
                     q = (uint32_t)it;
                     const uint32_t iw = IU[at64(IU_COUNT, IU_M, it)];
                     o = mk(Pst[at64(PF_COUNT, PF_O + 0, ps)], Pst[at64(PF_COUNT, PF_O + 1, ps)], Pst[at64(PF_COUNT, PF_O + 2, ps)]);
                     model_i = iw & 0xFFFFu;
+                    {   // tDelta = (step sign * cell size) / direction (core.rs:119-125; the product with +-1 is exact)
+                        const gptr<double> mc = (gptr<double>)models_g[model_i].cell;
+                        const double cx_ = mc[0], cy_ = mc[1], cz_ = mc[2];
+                        tdx = ((iw & IM_SX) ? cx_ : -cx_) / d.x;
+                        tdy = ((iw & IM_SY) ? cy_ : -cy_) / d.y;
+                        tdz = ((iw & IM_SZ) ? cz_ : -cz_) / d.z;
+                    }
                     const uint32_t mw = model_i < (uint32_t)kModelTab ? mtab[model_i] : (models_g[model_i].n | ((models_g[model_i].cell_base >> 5) << 10));
                     bm = kNoId; btri = kNoId; bt = 0.0;
                     if (STATS) dg_ray_its = 0;
