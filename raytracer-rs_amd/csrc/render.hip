@@ -793,8 +793,10 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const uint32_t rounds = 2 + std::max<uint32_t>(p->max_bounces, 1) * B_rounds;
     const dim3 block(256);
     const uint32_t shade_wgs = nq / 4u;
-    // (a small chunk's launches are latency-bound: three workgroups per CU leave room for the other chunk's waves; measured)
-    const uint32_t trace_wgs = (uint32_t)g_num_cus * (g_front_trace_wgs_env ? g_front_trace_wgs_per_cu : (np_max >= ((size_t)8 << 20) ? (uint32_t)RTM_FRONT_OCC : 3u));
+    const bool dense = sd->n_long_cells * 2 >= sd->n_nonempty_cells && sd->n_long_cells > 0;  // most non-empty cells are long (config 5's soup)
+    // (three trace workgroups per CU, not the four that fit: alone the kernel is 9 % slower with three waves per SIMD, but the
+    // fourth slot lets the other chunk's shade waves run beside it -- the frame is 1 % faster with two chunks in flight; measured)
+    const uint32_t trace_wgs = (uint32_t)g_num_cus * (g_front_trace_wgs_env ? g_front_trace_wgs_per_cu : (n_conc > 1 && !dense ? 3u : (uint32_t)RTM_FRONT_OCC));  // (the soup's trace launches are long and bound by issue: four)
     const bool all_lds = occ_words != 0u || sd->occ7_words == 0u;  // the bitmaps the walk probes are staged in LDS
     const bool occ_plain_only = all_lds && occ_words != sd->occ7_words;
     // The chunks run n_conc at a time, each on its own stream and work-space slot, and their launches are ENQUEUED round by
@@ -818,7 +820,6 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             // Scenes where most non-empty cells are long (config 5's soup): the box screen leaves about two entries per cell and every
             // cell a ray meets is opened, so two test slots per step and an earlier switch from walking to testing (soup -12 %);
             // a scene with a few long cells (suzanne: lists up to 37) keeps the settings of short lists.
-            const bool dense = sd->n_long_cells * 2 >= sd->n_nonempty_cells && sd->n_long_cells > 0;
             A.refill = g_front_refill; A.t_test_frac = dense ? g_t_test_frac_long : g_t_test_frac;
             A.wide = g_front_wide ? g_front_wide : (dense ? 2u : (uint32_t)RTM_FTRI_WIDE); A.t_min_lanes = g_t_min_lanes;
             A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
