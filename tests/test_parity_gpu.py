@@ -131,6 +131,19 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("no_such_knob", 1)
 
 
+def test_wide_frames_many_samples_and_packed_path_ids(rtm_gpu, rtm_scene):
+    """A path's (pixel of its tile, tile column, tile row of the chunk, sample) travel packed in one word (rt_front.h
+    PU_HOME) and the rows of a chunk are bounded so that it fits: 4096 columns x 200 samples leave two bits for the tile
+    row (chunks of four bands), 2050 x 33 is ragged in both directions.  The ray-front path must give the bits of the
+    single-kernel formulation, which has no such word."""
+    s = rtm_scene("simple_sphere")
+    for (w, h, spp) in ((4096, 48, 200), (2050, 35, 33), (9, 9, 1)):
+        a = s.render(spp=spp, seed=5, width=w, height=h)
+        b = s.render(spp=spp, seed=5, width=w, height=h, kernel_wave=True)
+        assert np.array_equal(a["rgb"], b["rgb"]), (w, h, spp)
+        assert np.array_equal(a["obj_id"], b["obj_id"])
+
+
 def test_timed_events(rtm_gpu, rtm_scene):
     """rtm_timed_events_collect: one event pair per trace launch of ordinary frames, and none when switched off."""
     s = rtm_scene("suzanne")
