@@ -133,7 +133,9 @@ const char* rtm_version(void);
  *   "front_steal"      sub-queues of other waves a trace wave may try when its own are empty (default 8),
  *   "front_timed_events"  1: event pairs around the trace launches of ordinary frames (rtm_timed_events_collect),
  *   "front_coop"       1 (default): when at most four rays of a wave are testing triangles, its other lanes test
- *                      their cells' entries for them.
+ *                      their cells' entries for them,
+ *   "front_rehit"      1 (default): in scenes with at most four spheres and planes the analytic hit of a path query is
+ *                      computed again when its answer is taken instead of travelling with the path (12 bytes per path and round).
  * Returns RTM_ERR_INVALID for an unknown key or a value out of range.  The same knobs are read from the
  * environment (RTM_FRONT_MAX_PATHS, ...) by rtm_init. */
 int rtm_set_tuning(const char* key, long long value);

@@ -56,6 +56,7 @@ static bool g_front_debug_rounds = false;
 static bool g_front_timed_events = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_front_ev_pool;
 static size_t g_front_ev_used = 0;
+static uint32_t g_front_rehit = 1;  // shade kernel: scenes with at most four spheres + planes recompute a path query's analytic hit instead of carrying it; env RTM_FRONT_REHIT
 static uint32_t g_front_coop = 1;  // trace kernel: idle lanes test the entries of the last one or two testing rays of a wave
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
 static uint32_t g_front_refill = 24, g_front_cull = 1, g_front_shade_waves_per_cu = 24;  // shade waves per CU: a multiple of 4
@@ -346,6 +347,7 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_CLAIM")) g_front_claim = (uint32_t)std::max(16, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_COOP")) g_front_coop = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("RTM_FRONT_REHIT")) g_front_rehit = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_STEAL")) g_front_steal = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
     g_front_debug_rounds = std::getenv("RTM_FRONT_DEBUG_ROUNDS") != nullptr;
@@ -377,6 +379,7 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
     if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
     if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
+    if (k == "front_rehit" && (value == 0 || value == 1)) { g_front_rehit = (uint32_t)value; return RTM_OK; }
     if (k == "front_timed_events" && (value == 0 || value == 1)) { g_front_timed_events = value != 0; return RTM_OK; }
     if (k == "front_steal" && value >= 0 && value <= 4096) { g_front_steal = (uint32_t)value; return RTM_OK; }
     if (k == "front_streams" && value >= 0 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
@@ -822,7 +825,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             // a scene with a few long cells (suzanne: lists up to 37) keeps the settings of short lists.
             A.refill = g_front_refill; A.t_test_frac = dense ? g_t_test_frac_long : g_t_test_frac;
             A.wide = g_front_wide ? g_front_wide : (dense ? 2u : (uint32_t)RTM_FTRI_WIDE); A.t_min_lanes = g_t_min_lanes;
-            A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop;
+            A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
             A.occ_words = occ_words;
             A.occ_plain = occ_plain_only ? 1u : 0u;
             // which bitmap word the walk probes (rt_front.h probe()): the arrival direction's, the plain occupancy when

@@ -109,6 +109,7 @@ struct FrontArgs {
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
     uint32_t coop;              // trace kernel: 1 = when at most four rays of a wave are testing, the other lanes test their entries
     uint32_t t_test_frac, t_min_lanes;
+    uint32_t rehit;             // shade kernel: 1 = the analytic hit of a path query is computed again when its answer is taken (few primitives)
     uint32_t wide;              // trace kernel: list entries a lane tests per step (at most RTM_FTRI_WIDE)
     uint32_t occ_words;         // bitmap words the trace kernel stages in LDS: all of g_occ7 (occ_plain = 0) or its plain occupancy alone
     uint32_t occ_plain;         // 1: only the plain occupancy (slot 6 of every group of eight words) is staged, one word per 32 cells
@@ -260,6 +261,57 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         const uint32_t yy = A.row_begin + ly * A.row_stride;
         const uint32_t pixel = x + A.W * yy;  // main.rs:160-161,177
 
+        // The analytic primitives of a query (core.rs:183-210): closest sphere / plane hit of the ray (org, dir), ties to the
+        // lower object index.  Used when a query is made and -- in scenes with a handful of primitives (A.rehit) -- again when
+        // its answer is taken: the same instructions on the same operands give the same bits, and 12 bytes per path and round
+        // stay out of the streamed state (`count`: the work counters see the query once).
+        auto analytic = [&](const V3 org, const V3 dir, const bool count, double& best, bool& found, uint32_t& b_obj, uint32_t& b_mat,
+                            uint32_t& b_kp) __attribute__((always_inline)) {
+            auto consider = [&](double t, uint32_t obj, uint32_t mt, uint32_t kp) __attribute__((always_inline)) {
+                if (t <= kEps) return;  // core.rs:75-77
+                if (t < best || (found && t == best && obj < b_obj)) {
+                    best = t; found = true;
+                    b_obj = obj; b_mat = mt; b_kp = kp;
+                }
+            };
+            const double a = dot(dir, dir);
+            // Solid::Sphere (core.rs:183-195), four at a time: the discriminants are evaluated together (their
+            // operands are loaded together), then the few spheres the ray meets take the root, in scene order
+            for (uint32_t i0 = 0; i0 < S.n_spheres; i0 += 4u) {
+                double disc[4], bb[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t i = min(i0 + u, S.n_spheres - 1u);  // (a batch past the end repeats the last sphere, unused)
+                    const double cx = sph_c[i * 4u], cy = sph_c[i * 4u + 1u], cz = sph_c[i * 4u + 2u], r = sph_c[i * 4u + 3u];
+                    const V3 oc = org - mk(cx, cy, cz);
+                    bb[u] = 2.0 * dot(dir, oc);
+                    const double c = dot(oc, oc) - r * r;
+                    disc[u] = bb[u] * bb[u] - 4.0 * a * c;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t i = i0 + u;
+                    if (i < S.n_spheres) {
+                        if (STATS && count) cnt.v[C_SPHERE]++;
+                        if (!(disc[u] < 0.0)) {
+                            const double t = (-bb[u] - __builtin_sqrt(disc[u])) / (2.0 * a);
+                            consider(t, sph_ids_c[i * 2 + 1], sph_ids_c[i * 2], i);
+                        }
+                    }
+                }
+            }
+            for (uint32_t i = 0; i < S.n_planes; ++i) {
+                if (STATS && count) cnt.v[C_PLANE]++;
+                const cptr<double> pp = pl_c + (size_t)i * 4;
+                const V3 pn = ld3(pp);
+                const double dv = dot(pn, dir);
+                if (fabs(dv) < kEps) continue;
+                const V3 center = pn * pp[3];
+                const double t = dot(center - org, pn) / dv;
+                if (t < kEps) continue;
+                consider(t, pl_ids_c[i * 2 + 1], pl_ids_c[i * 2], (1u << 30) | i);
+            }
+        };
         // what this round produces, and the state that travels on
         bool cont = false;  // the path stays alive
         bool go0 = false, go1 = false, go2 = false;
@@ -292,8 +344,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 fl = flb & ((1u << FB_BOUNCE_SHIFT) - 1u);
                 bounce = flb >> FB_BOUNCE_SHIFT;
                 o = ldD3(PF_O);
-                ba0 = ldD(PF_BA0);
-                h_kp = ldU(PU_HKP);
+                if (!A.rehit) { ba0 = ldD(PF_BA0); h_kp = ldU(PU_HKP); }
                 mat = ldU(PU_MAT);
                 if (nL > 2u) { held_t = ldD(PF_HELD); held_tri = ldU(PU_HTRI); held_m = ldU(PU_HM); li = ldU(PU_LI); }  // (only then can a result be held)
                 eff0 = ldD(PF_EFF); eff1 = ldD(PF_EFF + 1);
@@ -342,9 +393,18 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 }
                 // ---- 1. the path query: analytic hit, then the model hit the trace kernel found (core.rs:75-83)
                 if (b_take) {
-                    best0 = ba0;
-                    found0 = (fl & FB_FOUND0) != 0u;
-                    if (found0) prim_ids(h_kp, h_mat, h_obj);
+                    if (A.rehit) {  // the analytic part of the query again, from the ray the state holds
+                        double rb = __builtin_inf();
+                        bool rf = false;
+                        uint32_t ro = kNoId, rm = 0u, rk = 0u;
+                        analytic(o, dir0, false, rb, rf, ro, rm, rk);
+                        best0 = rb; found0 = rf; h_kp = rk;
+                        if (rf) { h_mat = rm; h_obj = ro; }
+                    } else {
+                        best0 = ba0;
+                        found0 = (fl & FB_FOUND0) != 0u;
+                        if (found0) prim_ids(h_kp, h_mat, h_obj);
+                    }
                     if ((fl & FB_TQ0) && r0.model != kNoId) {
                         const uint32_t m = r0.model;
                         const double t = r0.t;
@@ -481,50 +541,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 double best = __builtin_inf();
                 bool found = false;
                 uint32_t b_obj = kNoId, b_mat = 0, b_kp = 0;
-                auto consider = [&](double t, uint32_t obj, uint32_t mt, uint32_t kp) __attribute__((always_inline)) {
-                    if (t <= kEps) return;  // core.rs:75-77
-                    if (t < best || (found && t == best && obj < b_obj)) {
-                        best = t; found = true;
-                        b_obj = obj; b_mat = mt; b_kp = kp;
-                    }
-                };
-                const double a = dot(dir, dir);
-                // Solid::Sphere (core.rs:183-195), four at a time: the discriminants are evaluated together (their
-                // operands are loaded together), then the few spheres the ray meets take the root, in scene order
-                for (uint32_t i0 = 0; i0 < S.n_spheres; i0 += 4u) {
-                    double disc[4], bb[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) {
-                        const uint32_t i = min(i0 + u, S.n_spheres - 1u);  // (a batch past the end repeats the last sphere, unused)
-                        const double cx = sph_c[i * 4u], cy = sph_c[i * 4u + 1u], cz = sph_c[i * 4u + 2u], r = sph_c[i * 4u + 3u];
-                        const V3 oc = o - mk(cx, cy, cz);
-                        bb[u] = 2.0 * dot(dir, oc);
-                        const double c = dot(oc, oc) - r * r;
-                        disc[u] = bb[u] * bb[u] - 4.0 * a * c;
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) {
-                        const uint32_t i = i0 + u;
-                        if (i < S.n_spheres) {
-                            if (STATS) cnt.v[C_SPHERE]++;
-                            if (!(disc[u] < 0.0)) {
-                                const double t = (-bb[u] - __builtin_sqrt(disc[u])) / (2.0 * a);
-                                consider(t, sph_ids_c[i * 2 + 1], sph_ids_c[i * 2], i);
-                            }
-                        }
-                    }
-                }
-                for (uint32_t i = 0; i < S.n_planes; ++i) {
-                    if (STATS) cnt.v[C_PLANE]++;
-                    const cptr<double> pp = pl_c + (size_t)i * 4;
-                    const V3 pn = ld3(pp);
-                    const double dv = dot(pn, dir);
-                    if (fabs(dv) < kEps) continue;
-                    const V3 center = pn * pp[3];
-                    const double t = dot(center - o, pn) / dv;
-                    if (t < kEps) continue;
-                    consider(t, pl_ids_c[i * 2 + 1], pl_ids_c[i * 2], (1u << 30) | i);
-                }
+                analytic(o, dir, true, best, found, b_obj, b_mat, b_kp);
                 bool models = true;
                 if (j == 0u) {
                     ba0 = best;
@@ -609,10 +626,12 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         if (valid && cont) {  // the state moves on
             stD3(PF_COL, col); stD(PF_ATT, att);
             stD3(PF_O, o); stD3(PF_D0, dir0);
-            stD(PF_BA0, ba0); stD(PF_EFF, eff0); stD(PF_EFF + 1, eff1);
+            if (!A.rehit) stD(PF_BA0, ba0);
+            stD(PF_EFF, eff0); stD(PF_EFF + 1, eff1);
             if (nL > 2u) { stD3(PF_NRM, nn); stD3(PF_DIFF, diff); stD(PF_HELD, held_t); stU(PU_HTRI, held_tri); stU(PU_HM, held_m); stU(PU_LI, li); }
             stU(PU_FLB, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT) | (bounce << FB_BOUNCE_SHIFT));
-            stU(PU_HKP, h_kp); stU(PU_MAT, mat);
+            if (!A.rehit) stU(PU_HKP, h_kp);
+            stU(PU_MAT, mat);
             stU(PU_HOME, home);
         }
 #ifdef RTM_SHADE_TIMES
