@@ -825,7 +825,7 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             // a scene with a few long cells (suzanne: lists up to 37) keeps the settings of short lists.
             A.refill = g_front_refill; A.t_test_frac = dense ? g_t_test_frac_long : g_t_test_frac;
             A.wide = g_front_wide ? g_front_wide : (dense ? 2u : (uint32_t)RTM_FTRI_WIDE); A.t_min_lanes = g_t_min_lanes;
-            A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
+            A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop; A.att_replay = (p->max_bounces <= 16u && sd->view.n_materials <= 0xFFFFu) ? g_front_rehit : 0u; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
             A.occ_words = occ_words;
             A.occ_plain = occ_plain_only ? 1u : 0u;
             // which bitmap word the walk probes (rt_front.h probe()): the arrival direction's, the plain occupancy when

@@ -109,6 +109,7 @@ struct FrontArgs {
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
     uint32_t coop;              // trace kernel: 1 = when at most four rays of a wave are testing, the other lanes test their entries
     uint32_t t_test_frac, t_min_lanes;
+    uint32_t att_replay;        // shade kernel: 1 = the attenuation is multiplied up again from the vertices' metal flags (16 bits beside the material) instead of travelling as a double
     uint32_t rehit;             // shade kernel: 1 = the analytic hit of a path query is computed again when its answer is taken (few primitives)
     uint32_t wide;              // trace kernel: list entries a lane tests per step (at most RTM_FTRI_WIDE)
     uint32_t occ_words;         // bitmap words the trace kernel stages in LDS: all of g_occ7 (occ_plain = 0) or its plain occupancy alone
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         bool cont = false;  // the path stays alive
         bool go0 = false, go1 = false, go2 = false;
         V3 o = mk(0, 0, 0), dir0 = mk(0, 0, 1), nn = mk(0, 0, 1), col = mk(0, 0, 0), diff = mk(0, 0, 0);
+        uint32_t hist = 0;  // (A.att_replay) bit k: vertex k was metal -- the attenuation is the product of the vertices' factors, in order
         double att = 1.0, ba0 = 0.0, eff0 = 0.0, eff1 = 0.0, held_t = 0.0;
         uint32_t fl = 0, bounce = 0, li = 0, n_sh = 0, mat = 0, held_tri = kNoId, held_m = kNoId;
         uint32_t h_obj = kNoId, h_mat = 0, h_kp = 0, h_tri = kNoId;  // slot 0's hit (h_kp travels on while the model answer is pending)
@@ -346,12 +348,13 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 o = ldD3(PF_O);
                 if (!A.rehit) { ba0 = ldD(PF_BA0); h_kp = ldU(PU_HKP); }
                 mat = ldU(PU_MAT);
+                if (A.att_replay) { hist = mat >> 16; mat &= 0xFFFFu; }
                 if (nL > 2u) { held_t = ldD(PF_HELD); held_tri = ldU(PU_HTRI); held_m = ldU(PU_HM); li = ldU(PU_LI); }  // (only then can a result be held)
                 eff0 = ldD(PF_EFF); eff1 = ldD(PF_EFF + 1);
                 if (nL > 2u) nn = ldD3(PF_NRM);
                 dir0 = ldD3(PF_D0);
                 col = ldD3(PF_COL);
-                att = ldD(PF_ATT);
+                if (!A.att_replay) att = ldD(PF_ATT);
                 if (nL > 2u) diff = ldD3(PF_DIFF);
             }
         }
@@ -380,6 +383,10 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         if (valid) {
             if (!ROUND0) {
                 if (fl & FB_HELD) { r0.t = held_t; r0.tri = held_tri; r0.model = held_m; }  // slot 0's answer came in an earlier round
+                if (A.att_replay) {  // main.rs:118,124: the same multiplications in the same order as when the vertices were finished
+                    att = 1.0;
+                    for (uint32_t kb = 0; kb < bounce; ++kb) att = att * (((hist >> kb) & 1u) ? 0.8 : 0.1);
+                }
                 // ---- 0. decisions
                 const bool a_v = (fl & FB_HASV) != 0u;
                 const uint32_t n_in = a_v ? ((fl >> FB_NSH_SHIFT) & 3u) : 0u;  // shadow results to consume
@@ -463,6 +470,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 if (a_fin) {
                     col = col + mk(mat_at(mat_old, 0), mat_at(mat_old, 1), mat_at(mat_old, 2)) * att * (diff * (metal_old ? 0.2 : 0.9));
                     att = att * (metal_old ? 0.8 : 0.1);
+                    hist |= (metal_old ? 1u : 0u) << (bounce & 15u);
                     ++bounce;
                     fl &= ~FB_HASV;
                 }
@@ -624,14 +632,15 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         const unsigned long long st_d = __builtin_amdgcn_s_memtime();
 #endif
         if (valid && cont) {  // the state moves on
-            stD3(PF_COL, col); stD(PF_ATT, att);
+            stD3(PF_COL, col);
+            if (!A.att_replay) stD(PF_ATT, att);
             stD3(PF_O, o); stD3(PF_D0, dir0);
             if (!A.rehit) stD(PF_BA0, ba0);
             stD(PF_EFF, eff0); stD(PF_EFF + 1, eff1);
             if (nL > 2u) { stD3(PF_NRM, nn); stD3(PF_DIFF, diff); stD(PF_HELD, held_t); stU(PU_HTRI, held_tri); stU(PU_HM, held_m); stU(PU_LI, li); }
             stU(PU_FLB, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT) | (bounce << FB_BOUNCE_SHIFT));
             if (!A.rehit) stU(PU_HKP, h_kp);
-            stU(PU_MAT, mat);
+            stU(PU_MAT, A.att_replay ? (mat | (hist << 16)) : mat);
             stU(PU_HOME, home);
         }
 #ifdef RTM_SHADE_TIMES
