@@ -72,7 +72,7 @@ static FrontWorkspace g_front_ws;
 static std::atomic<bool> g_render_busy{false};
 static hipEvent_t g_frame_done = nullptr;
 static bool g_frame_done_valid = false;
-static size_t g_front_max_paths = 32u << 20;  // paths per band (668 B of workspace each); env RTM_FRONT_MAX_PATHS
+static size_t g_front_max_paths = 32u << 20;  // paths per band (628 B of workspace each); env RTM_FRONT_MAX_PATHS
 static uint32_t g_s_threshold = 24, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------

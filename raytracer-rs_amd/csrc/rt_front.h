@@ -49,7 +49,8 @@ constexpr uint32_t kRemGuards = (1u << 9) | (1u << 19) | (1u << 29);  // see `re
 // field f of path p is D[at64(PF_COUNT, f, p)] (likewise U, the query results and the trace items).  A wave's
 // accesses of one iteration are 512-byte runs inside ONE ~10 KB region; with whole-frame SoA arrays (hundreds of MB
 // apart) every field sat on its own page and address translation, not HBM, set the pace of the shade kernel.
-// Only what the next round cannot recompute travels: 13 doubles and 4 words per live path in scenes with at most two
+// Only what the next round cannot recompute travels: 13 doubles and 4 words per live path (11 and 3 with A.rehit and
+// A.att_replay: PF_BA0, PF_ATT and PU_HKP are then neither written nor read) in scenes with at most two
 // lights (the fields behind PF_EFF / PU_HOME exist for scenes with more, where a vertex waits through several rounds).
 enum : int {
     PF_COL = 0,    // colour accumulated along the path (main.rs:59)
