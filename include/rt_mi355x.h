@@ -135,7 +135,8 @@ const char* rtm_version(void);
  *   "front_coop"       1 (default): when at most four rays of a wave are testing triangles, its other lanes test
  *                      their cells' entries for them,
  *   "front_rehit"      1 (default): in scenes with at most four spheres and planes the analytic hit of a path query is
- *                      computed again when its answer is taken instead of travelling with the path (12 bytes per path and round).
+ *                      computed again when its answer is taken instead of travelling with the path (12 bytes per path and round),
+ *                      and for up to 16 bounces the attenuation is multiplied up again from the vertices' metal flags (8 bytes).
  * Returns RTM_ERR_INVALID for an unknown key or a value out of range.  The same knobs are read from the
  * environment (RTM_FRONT_MAX_PATHS, ...) by rtm_init. */
 int rtm_set_tuning(const char* key, long long value);
