@@ -16,6 +16,7 @@
 #include "rt_device.h"
 #include "rt_wave.h"
 #include "rt_front.h"
+#include "rt_pool.h"
 
 #pragma clang fp contract(off)
 
@@ -56,6 +57,9 @@ static bool g_front_debug_rounds = false;
 static bool g_front_timed_events = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_front_ev_pool;
 static size_t g_front_ev_used = 0;
+static uint32_t g_front_pool = 1;  // trace kernel: 1 = rays parked in LDS pools (rt_pool.h) when the scene's bitmaps leave room for them, 0 = one ray per lane (rt_front.h); env RTM_FRONT_POOL
+static uint32_t g_pool_refill = 40, g_pool_walk_more = 40, g_pool_test_frac = 32;  // env RTM_POOL_REFILL / RTM_POOL_WALK_MORE / RTM_POOL_TEST_FRAC
+constexpr int kPoolRays = 96;  // rays per wave of the pool kernel
 static uint32_t g_front_rehit = 1;  // shade kernel: scenes with at most four spheres + planes recompute a path query's analytic hit instead of carrying it; env RTM_FRONT_REHIT
 static uint32_t g_front_coop = 1;  // trace kernel: idle lanes test the entries of the last one or two testing rays of a wave
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
@@ -347,6 +351,10 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_REFILL")) g_front_refill = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_CLAIM")) g_front_claim = (uint32_t)std::max(16, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_COOP")) g_front_coop = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("RTM_FRONT_POOL")) g_front_pool = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("RTM_POOL_REFILL")) g_pool_refill = (uint32_t)std::max(1, std::min(kPoolRays, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_POOL_WALK_MORE")) g_pool_walk_more = (uint32_t)std::max(1, std::min(65, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_POOL_TEST_FRAC")) g_pool_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_REHIT")) g_front_rehit = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_STEAL")) g_front_steal = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_SHADE_WAVES")) g_front_shade_waves_per_cu = (uint32_t)std::max(4, std::min(64, std::atoi(e) & ~3));
@@ -380,6 +388,10 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
     if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
     if (k == "front_rehit" && (value == 0 || value == 1)) { g_front_rehit = (uint32_t)value; return RTM_OK; }
+    if (k == "front_pool" && (value == 0 || value == 1)) { g_front_pool = (uint32_t)value; return RTM_OK; }
+    if (k == "pool_refill" && value >= 1 && value <= kPoolRays) { g_pool_refill = (uint32_t)value; return RTM_OK; }
+    if (k == "pool_walk_more" && value >= 1 && value <= 65) { g_pool_walk_more = (uint32_t)value; return RTM_OK; }
+    if (k == "pool_test_frac" && value >= 0 && value <= 64) { g_pool_test_frac = (uint32_t)value; return RTM_OK; }
     if (k == "front_timed_events" && (value == 0 || value == 1)) { g_front_timed_events = value != 0; return RTM_OK; }
     if (k == "front_steal" && value >= 0 && value <= 4096) { g_front_steal = (uint32_t)value; return RTM_OK; }
     if (k == "front_streams" && value >= 0 && value <= kFrontStreamsMax) { g_front_streams = (uint32_t)value; return RTM_OK; }
@@ -801,7 +813,17 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     // fourth slot lets the other chunk's shade waves run beside it -- the frame is 1 % faster with two chunks in flight; measured)
     const uint32_t trace_wgs = (uint32_t)g_num_cus * (g_front_trace_wgs_env ? g_front_trace_wgs_per_cu : (n_conc > 1 && !dense ? 3u : (uint32_t)RTM_FRONT_OCC));  // (the soup's trace launches are long and bound by issue: four)
     const bool all_lds = occ_words != 0u || sd->occ7_words == 0u;  // the bitmaps the walk probes are staged in LDS
-    const bool occ_plain_only = all_lds && occ_words != sd->occ7_words;
+    bool occ_plain_only = all_lds && occ_words != sd->occ7_words;
+    // The pool trace kernel (rt_pool.h): one 512-thread workgroup per CU holds the bitmaps once and a pool of kPoolRays rays per
+    // wave in LDS.  It needs the probed bitmaps in LDS; when all seven do not fit beside the pools, the plain occupancy alone is staged.
+    const bool pool_multi = sd->view.n_models > 1, pool_long = sd->n_long_cells != 0;
+    constexpr size_t kLdsDynMax = 160u * 1024u - rtf::kModelTab * 4u;
+    bool use_pool = g_front_pool != 0u && all_lds && sd->view.n_models > 0;
+    if (use_pool && rtf::pool_lds_bytes(occ_words, kPoolRays, pool_long, pool_multi) > kLdsDynMax) {
+        if (sd->occ7_words && rtf::pool_lds_bytes(sd->occ7_words / 8u, kPoolRays, pool_long, pool_multi) <= kLdsDynMax) { occ_words = sd->occ7_words / 8u; occ_plain_only = true; }
+        else use_pool = false;
+    }
+    const size_t pool_lds = use_pool ? rtf::pool_lds_bytes(occ_words, kPoolRays, pool_long, pool_multi) : 0;
     // The chunks run n_conc at a time, each on its own stream and work-space slot, and their launches are ENQUEUED round by
     // round across the group: queued chunk after chunk, the second stream's first kernel reached the GPU only after the
     // host had queued all ~24 launches of the first chunk (0.9 ms into a 6.5 ms frame share).
@@ -823,7 +845,8 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
             // Scenes where most non-empty cells are long (config 5's soup): the box screen leaves about two entries per cell and every
             // cell a ray meets is opened, so two test slots per step and an earlier switch from walking to testing (soup -12 %);
             // a scene with a few long cells (suzanne: lists up to 37) keeps the settings of short lists.
-            A.refill = g_front_refill; A.t_test_frac = dense ? g_t_test_frac_long : g_t_test_frac;
+            A.pool_refill = g_pool_refill; A.pool_walk_more = g_pool_walk_more;
+            A.refill = g_front_refill; A.t_test_frac = use_pool ? g_pool_test_frac : (dense ? g_t_test_frac_long : g_t_test_frac);
             A.wide = g_front_wide ? g_front_wide : (dense ? 2u : (uint32_t)RTM_FTRI_WIDE); A.t_min_lanes = g_t_min_lanes;
             A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop; A.att_replay = (p->max_bounces <= 16u && sd->view.n_materials <= 0xFFFFu) ? g_front_rehit : 0u; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
             A.occ_words = occ_words;
@@ -896,6 +919,27 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     mark(1, false, stream);
                     const size_t lds = (size_t)occ_words * 4;
                     const int variant = (stats ? 4 : 0) | (all_lds ? 2 : 0) | (sd->n_long_cells ? 1 : 0);
+                    if (use_pool) {
+                        static bool attr_set[8] = {};  // (more than 64 KiB of dynamic LDS has to be asked for, once per kernel)
+                        const int pv = (stats ? 4 : 0) | (pool_long ? 2 : 0) | (pool_multi ? 1 : 0);
+                        switch (pv) {
+#define RTM_POOL_CASE(v, S_, L_, M_)                                                                                                        \
+    case v:                                                                                                                                 \
+        if (!attr_set[v]) {                                                                                                                 \
+            HIP_TRY(hipFuncSetAttribute((const void*)&rtf::pool_trace_kernel<S_, L_, M_, kPoolRays>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)kLdsDynMax));                                                                                  \
+            attr_set[v] = true;                                                                                                             \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL((rtf::pool_trace_kernel<S_, L_, M_, kPoolRays>), dim3((uint32_t)g_num_cus), dim3(rtf::kPoolBlock), pool_lds, stream, \
+                           sd->view, A, r, d_cnt);                                                                                          \
+        break;
+                            RTM_POOL_CASE(0, false, false, false) RTM_POOL_CASE(1, false, false, true)
+                            RTM_POOL_CASE(2, false, true, false) RTM_POOL_CASE(3, false, true, true)
+                            RTM_POOL_CASE(4, true, false, false) RTM_POOL_CASE(5, true, false, true)
+                            RTM_POOL_CASE(6, true, true, false) RTM_POOL_CASE(7, true, true, true)
+#undef RTM_POOL_CASE
+                        }
+                    } else
                     switch (variant) {
 #define RTM_TRACE_CASE(v, S_, L_, G_) \
     case v: hipLaunchKernelGGL((rtf::front_trace_kernel<S_, L_, G_>), dim3(trace_wgs), block, lds, stream, sd->view, A, r, d_cnt); break;

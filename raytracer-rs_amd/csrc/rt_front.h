@@ -113,6 +113,8 @@ struct FrontArgs {
     uint32_t att_replay;        // shade kernel: 1 = the attenuation is multiplied up again from the vertices' metal flags (16 bits beside the material) instead of travelling as a double
     uint32_t rehit;             // shade kernel: 1 = the analytic hit of a path query is computed again when its answer is taken (few primitives)
     uint32_t wide;              // trace kernel: list entries a lane tests per step (at most RTM_FTRI_WIDE)
+    uint32_t pool_refill;       // pool trace kernel (rt_pool.h): idle slots of a wave's pool that trigger a refill
+    uint32_t pool_walk_more;    // pool trace kernel: a walk batch goes on while at least this many of its lanes are still walking
     uint32_t occ_words;         // bitmap words the trace kernel stages in LDS: all of g_occ7 (occ_plain = 0) or its plain occupancy alone
     uint32_t occ_plain;         // 1: only the plain occupancy (slot 6 of every group of eight words) is staged, one word per 32 cells
     uint32_t occ_shift, occ_m1, occ_m2;  // bitmap word of cell c arriving from direction a: ((c >> 5) << occ_shift) + ((a & occ_m1) | occ_m2)
