@@ -57,9 +57,10 @@ static bool g_front_debug_rounds = false;
 static bool g_front_timed_events = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_front_ev_pool;
 static size_t g_front_ev_used = 0;
-static uint32_t g_front_pool = 1;  // trace kernel: 1 = rays parked in LDS pools (rt_pool.h) when the scene's bitmaps leave room for them, 0 = one ray per lane (rt_front.h); env RTM_FRONT_POOL
+static uint32_t g_front_pool = 0;  // trace kernel: 1 = rays parked in LDS pools (rt_pool.h) when the scene's bitmaps leave room for them, 0 = one ray per lane (rt_front.h); env RTM_FRONT_POOL
 static uint32_t g_pool_refill = 40, g_pool_walk_more = 40, g_pool_test_frac = 32;  // env RTM_POOL_REFILL / RTM_POOL_WALK_MORE / RTM_POOL_TEST_FRAC
-constexpr int kPoolRays = 96;  // rays per wave of the pool kernel
+static int g_pool_rays = 96;  // rays per wave of the pool kernel (72 or 96); env RTM_POOL_R
+static uint32_t g_pool_plain = 0, g_pool_waves = 0;  // env RTM_POOL_PLAIN=1: stage the plain occupancy only; RTM_POOL_WAVES: cap on waves per workgroup
 static uint32_t g_front_rehit = 1;  // shade kernel: scenes with at most four spheres + planes recompute a path query's analytic hit instead of carrying it; env RTM_FRONT_REHIT
 static uint32_t g_front_coop = 1;  // trace kernel: idle lanes test the entries of the last one or two testing rays of a wave
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
@@ -352,7 +353,10 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_CLAIM")) g_front_claim = (uint32_t)std::max(16, std::atoi(e));
     if (const char* e = std::getenv("RTM_FRONT_COOP")) g_front_coop = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_POOL")) g_front_pool = std::atoi(e) ? 1u : 0u;
-    if (const char* e = std::getenv("RTM_POOL_REFILL")) g_pool_refill = (uint32_t)std::max(1, std::min(kPoolRays, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_POOL_REFILL")) g_pool_refill = (uint32_t)std::max(1, std::min(128, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_POOL_R")) g_pool_rays = std::atoi(e) == 72 ? 72 : 96;
+    if (const char* e = std::getenv("RTM_POOL_PLAIN")) g_pool_plain = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("RTM_POOL_WAVES")) g_pool_waves = (uint32_t)std::max(0, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("RTM_POOL_WALK_MORE")) g_pool_walk_more = (uint32_t)std::max(1, std::min(65, std::atoi(e)));
     if (const char* e = std::getenv("RTM_POOL_TEST_FRAC")) g_pool_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_REHIT")) g_front_rehit = std::atoi(e) ? 1u : 0u;
@@ -389,7 +393,7 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
     if (k == "front_rehit" && (value == 0 || value == 1)) { g_front_rehit = (uint32_t)value; return RTM_OK; }
     if (k == "front_pool" && (value == 0 || value == 1)) { g_front_pool = (uint32_t)value; return RTM_OK; }
-    if (k == "pool_refill" && value >= 1 && value <= kPoolRays) { g_pool_refill = (uint32_t)value; return RTM_OK; }
+    if (k == "pool_refill" && value >= 1 && value <= 128) { g_pool_refill = (uint32_t)value; return RTM_OK; }
     if (k == "pool_walk_more" && value >= 1 && value <= 65) { g_pool_walk_more = (uint32_t)value; return RTM_OK; }
     if (k == "pool_test_frac" && value >= 0 && value <= 64) { g_pool_test_frac = (uint32_t)value; return RTM_OK; }
     if (k == "front_timed_events" && (value == 0 || value == 1)) { g_front_timed_events = value != 0; return RTM_OK; }
@@ -819,11 +823,22 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
     const bool pool_multi = sd->view.n_models > 1, pool_long = sd->n_long_cells != 0;
     constexpr size_t kLdsDynMax = 160u * 1024u - rtf::kModelTab * 4u;
     bool use_pool = g_front_pool != 0u && all_lds && sd->view.n_models > 0;
-    if (use_pool && rtf::pool_lds_bytes(occ_words, kPoolRays, pool_long, pool_multi) > kLdsDynMax) {
-        if (sd->occ7_words && rtf::pool_lds_bytes(sd->occ7_words / 8u, kPoolRays, pool_long, pool_multi) <= kLdsDynMax) { occ_words = sd->occ7_words / 8u; occ_plain_only = true; }
-        else use_pool = false;
+    uint32_t pool_waves = 0;
+    auto waves_for = [&](uint32_t words) {
+        const size_t bm = ((size_t)words * 4 + 15) & ~(size_t)15;
+        if (bm >= kLdsDynMax) return 0u;
+        const uint32_t w = (uint32_t)std::min<size_t>(16, (kLdsDynMax - bm) / rtf::pool_wave_bytes(g_pool_rays, pool_long, pool_multi));
+        return g_pool_waves ? std::min(w, g_pool_waves) : w;
+    };
+    if (use_pool) {
+        pool_waves = g_pool_plain ? 0u : waves_for(occ_words);
+        if (pool_waves < 8u && sd->occ7_words) {  // the plain occupancy alone leaves room for more waves
+            const uint32_t w2 = waves_for(sd->occ7_words / 8u);
+            if (w2 > pool_waves) { pool_waves = w2; occ_words = sd->occ7_words / 8u; occ_plain_only = true; }
+        }
+        if (pool_waves < 4u) use_pool = false;
     }
-    const size_t pool_lds = use_pool ? rtf::pool_lds_bytes(occ_words, kPoolRays, pool_long, pool_multi) : 0;
+    const size_t pool_lds = use_pool ? rtf::pool_lds_bytes(occ_words, g_pool_rays, pool_long, pool_multi, pool_waves) : 0;
     // The chunks run n_conc at a time, each on its own stream and work-space slot, and their launches are ENQUEUED round by
     // round across the group: queued chunk after chunk, the second stream's first kernel reached the GPU only after the
     // host had queued all ~24 launches of the first chunk (0.9 ms into a 6.5 ms frame share).
@@ -920,23 +935,28 @@ int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, 
                     const size_t lds = (size_t)occ_words * 4;
                     const int variant = (stats ? 4 : 0) | (all_lds ? 2 : 0) | (sd->n_long_cells ? 1 : 0);
                     if (use_pool) {
-                        static bool attr_set[8] = {};  // (more than 64 KiB of dynamic LDS has to be asked for, once per kernel)
                         const int pv = (stats ? 4 : 0) | (pool_long ? 2 : 0) | (pool_multi ? 1 : 0);
                         switch (pv) {
+#define RTM_POOL_LAUNCH(v, S_, L_, M_, R_)                                                                                                  \
+    {                                                                                                                                       \
+        static bool attr_set = false;                                                                                                       \
+        if (!attr_set) {                                                                                                                    \
+            HIP_TRY(hipFuncSetAttribute((const void*)&rtf::pool_trace_kernel<S_, L_, M_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                        (int)kLdsDynMax));                                                                                  \
+            attr_set = true;                                                                                                                \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL((rtf::pool_trace_kernel<S_, L_, M_, R_>), dim3((uint32_t)g_num_cus), dim3(pool_waves * 64u), pool_lds, stream,   \
+                           sd->view, A, r, d_cnt);                                                                                          \
+    }
 #define RTM_POOL_CASE(v, S_, L_, M_)                                                                                                        \
     case v:                                                                                                                                 \
-        if (!attr_set[v]) {                                                                                                                 \
-            HIP_TRY(hipFuncSetAttribute((const void*)&rtf::pool_trace_kernel<S_, L_, M_, kPoolRays>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        (int)kLdsDynMax));                                                                                  \
-            attr_set[v] = true;                                                                                                             \
-        }                                                                                                                                   \
-        hipLaunchKernelGGL((rtf::pool_trace_kernel<S_, L_, M_, kPoolRays>), dim3((uint32_t)g_num_cus), dim3(rtf::kPoolBlock), pool_lds, stream, \
-                           sd->view, A, r, d_cnt);                                                                                          \
+        if (g_pool_rays == 72) RTM_POOL_LAUNCH(v, S_, L_, M_, 72) else RTM_POOL_LAUNCH(v, S_, L_, M_, 96)                                   \
         break;
                             RTM_POOL_CASE(0, false, false, false) RTM_POOL_CASE(1, false, false, true)
                             RTM_POOL_CASE(2, false, true, false) RTM_POOL_CASE(3, false, true, true)
                             RTM_POOL_CASE(4, true, false, false) RTM_POOL_CASE(5, true, false, true)
                             RTM_POOL_CASE(6, true, true, false) RTM_POOL_CASE(7, true, true, true)
+#undef RTM_POOL_LAUNCH
 #undef RTM_POOL_CASE
                         }
                     } else

@@ -23,7 +23,7 @@
 
 namespace rtf {
 
-constexpr int kPoolBlock = 512;     // 8 waves per workgroup, one workgroup per CU: the bitmaps are staged once per CU
+constexpr int kPoolBlockMax = 1024;  // one workgroup per CU (the bitmaps are staged once per CU), as many waves as the pools leave LDS for
 constexpr int kPoolWalkSteps = 4;   // DDA steps of a walk batch before the lanes still walking are counted
 constexpr int kPoolWalkMore = 4;    // ... further pairs of steps while enough of them are left
 
@@ -43,12 +43,12 @@ enum : uint32_t {
 constexpr int pool_nd(bool multi) { return multi ? 14 : 13; }
 constexpr int pool_nu(bool has_long, bool multi) { return (int)PW_EXTRA + (has_long ? 1 : 0) + (multi ? 2 : 0); }
 constexpr size_t pool_wave_bytes(int R, bool has_long, bool multi) { return (size_t)R * (size_t)(pool_nd(multi) * 8 + pool_nu(has_long, multi) * 4) + 256u; }
-constexpr size_t pool_lds_bytes(uint32_t occ_words, int R, bool has_long, bool multi) {
-    return (((size_t)occ_words * 4 + 15) & ~(size_t)15) + (size_t)(kPoolBlock / 64) * pool_wave_bytes(R, has_long, multi);
+constexpr size_t pool_lds_bytes(uint32_t occ_words, int R, bool has_long, bool multi, uint32_t waves) {
+    return (((size_t)occ_words * 4 + 15) & ~(size_t)15) + (size_t)waves * pool_wave_bytes(R, has_long, multi);
 }
 
 template <bool STATS, bool HAS_LONG, bool MULTI, int R>
-__global__ __launch_bounds__(kPoolBlock) void pool_trace_kernel(RtmDevScene S, FrontArgs A, uint32_t round, unsigned long long* __restrict__ out_cnt) {
+__global__ __launch_bounds__(kPoolBlockMax) void pool_trace_kernel(RtmDevScene S, FrontArgs A, uint32_t round, unsigned long long* __restrict__ out_cnt) {
     static_assert(R > 64 && R <= 128 && R % 8 == 0, "pool size");
     extern __shared__ __attribute__((aligned(16))) uint32_t pool_lds[];  // [A.occ_words] bitmaps, then one pool per wave
     __shared__ uint32_t mtab[kModelTab];                                  // per model: cells per side | first scene cell / 32 << 10
@@ -56,11 +56,11 @@ __global__ __launch_bounds__(kPoolBlock) void pool_trace_kernel(RtmDevScene S, F
     constexpr int PW_WHI = PW_EXTRA, PW_BM = PW_EXTRA + (HAS_LONG ? 1 : 0), PW_BTRI = PW_BM + 1;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    for (uint32_t m = tid; m < min(S.n_models, (uint32_t)kModelTab); m += kPoolBlock)
+    for (uint32_t m = tid; m < min(S.n_models, (uint32_t)kModelTab); m += blockDim.x)
         mtab[m] = S.models[m].n | ((S.models[m].cell_base >> 5) << 10);
     {
         const gptr<uint32_t> src = as_global(S.g_occ7);
-        for (uint32_t i = tid; i < A.occ_words; i += kPoolBlock) pool_lds[i] = src[A.occ_plain ? i * 8u + 6u : i];
+        for (uint32_t i = tid; i < A.occ_words; i += blockDim.x) pool_lds[i] = src[A.occ_plain ? i * 8u + 6u : i];
     }
     const uint32_t* const occ_lds = pool_lds;
     char* const pool_base = (char*)pool_lds + (((size_t)A.occ_words * 4 + 15) & ~(size_t)15) + (size_t)wave_in_wg * pool_wave_bytes(R, HAS_LONG, MULTI);
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(kPoolBlock) void pool_trace_kernel(RtmDevScene S, F
 
     // the wave's position in the queue (as in front_trace_kernel: own sub-queues first, claimed A.claim items at a time, then
     // up to A.steal sub-queues of other waves)
-    const uint32_t trace_waves = gridDim.x * (kPoolBlock / 64);
-    const uint32_t wave_id = blockIdx.x * (kPoolBlock / 64) + wave_in_wg;
+    const uint32_t trace_waves = gridDim.x * (blockDim.x / 64u);
+    const uint32_t wave_id = blockIdx.x * (blockDim.x / 64u) + wave_in_wg;
     uint32_t sq = wave_id, sq_items = 0, sq_n0 = 0, sq_n01 = 0, stolen = 0;
     bool stealing = false;
     uint32_t pool_next = 0, pool_end = 0;

@@ -377,6 +377,33 @@ def test_teapot_and_soup_scene(rtm_gpu, orc):
     assert (g["obj_id"] == 1).any() and (g["obj_id"] == 2).any()
 
 
+def test_pool_trace_kernel_gives_the_same_bits(rtm_gpu, rtm_scene, oracle_scene, orc):
+    """The trace kernel with its rays parked in per-wave LDS pools (rt_pool.h, rtm_set_tuning("front_pool", 1); measured
+    slower than the one-ray-per-lane kernel and therefore not the default): oracle bits, ids and counters on a single
+    model, on a model with long cells (suzanne: lists up to 37) and on two models (teapot + soup: the enter phase)."""
+    try:
+        rtm_gpu.set_tuning("front_pool", 1)
+        for name, spp in (("bunny", 4), ("suzanne", 3)):
+            ref = oracle_scene(name).render(spp=spp, seed=9, width=240, height=160)
+            g = rtm_scene(name).render(spp=spp, seed=9, width=240, height=160, stats=True)
+            assert_frames_match(g, ref, name + " pool")
+            assert g["counters"] == ref["counters"]
+            assert np.array_equal(rtm_scene(name).render(spp=spp, seed=9, width=240, height=160)["rgb"], ref["rgb"])  # culling on
+        txt = ('size 160 160\nplane (0, 1.0, 0) 2 metal:white\n'
+               'model "./models/teapot.obj" white > scale 0.4 > translate (0, 0.5, 6)\nlight (1, -2, 2) white\nlight (-2, -1, 3) orange')
+        a = rtm_gpu.Scene(text=txt, base_dir=ASSETS, synth_normals=True)
+        b = orc.OracleScene(text=txt, base_dir=ASSETS, allow_missing_normals=True)
+        pos, nrm = _soup(np.random.default_rng(3), 20000, (0, -1, 7), 2.0, 0.05)
+        a.add_triangles(pos, nrm)
+        b.add_triangles(pos, nrm)
+        g, c = a.render(spp=2, seed=1, stats=True), b.render(spp=2, seed=1)
+        assert_frames_match(g, c, "teapot+soup pool")
+        assert g["counters"] == c["counters"]
+        assert np.array_equal(a.render(spp=2, seed=1)["rgb"], c["rgb"])
+    finally:
+        rtm_gpu.set_tuning("front_pool", 0)
+
+
 def test_full_size_20spp_properties(rtm_gpu, rtm_scene):
     """BASELINE's headline size (bunny 1200x1200, 20 spp) is too slow for the CPU oracle inside a test, so it is
     checked through size-independent properties: determinism (same seed -> same bits), seed sensitivity, the
