@@ -112,6 +112,7 @@ struct FrontArgs {
     uint32_t t_test_frac, t_min_lanes;
     uint32_t att_replay;        // shade kernel: 1 = the attenuation is multiplied up again from the vertices' metal flags (16 bits beside the material) instead of travelling as a double
     uint32_t rehit;             // shade kernel: 1 = the analytic hit of a path query is computed again when its answer is taken (few primitives)
+    uint32_t inlane;            // shade kernel: paths whose queries were all settled without the trace kernel advance in the lane when at least this many lanes of the wave do (65 = never)
     uint32_t wide;              // trace kernel: list entries a lane tests per step (at most RTM_FTRI_WIDE)
     uint32_t pool_refill;       // pool trace kernel (rt_pool.h): idle slots of a wave's pool that trigger a refill
     uint32_t pool_walk_more;    // pool trace kernel: a walk batch goes on while at least this many of its lanes are still walking
@@ -323,9 +324,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         uint32_t hist = 0;  // (A.att_replay) bit k: vertex k was metal -- the attenuation is the product of the vertices' factors, in order
         double att = 1.0, ba0 = 0.0, eff0 = 0.0, eff1 = 0.0, held_t = 0.0;
         uint32_t fl = 0, bounce = 0, li = 0, n_sh = 0, mat = 0, held_tri = kNoId, held_m = kNoId;
-        uint32_t h_obj = kNoId, h_mat = 0, h_kp = 0, h_tri = kNoId;  // slot 0's hit (h_kp travels on while the model answer is pending)
-        double best0 = 0.0;
-        bool found0 = false;
+        uint32_t h_kp = 0;  // slot 0's analytic hit (travels on while the model answer is pending)
+        bool fresh0 = false;  // ba0 / h_kp / FB_FOUND0 were produced in this kernel (they are not read back in A.rehit mode)
 
         if (valid) {
             if (ROUND0) {
@@ -383,8 +383,23 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
 #endif
-        if (valid) {
-            if (!ROUND0) {
+        // A path advances IN THE LANE for as long as every answer it waits for is known without the trace kernel: a vertex whose
+        // bounce ray and shadow rays all miss the models' boxes is consumed in the next pass of this loop (its queries were
+        // settled by the analytic primitives when they were made) instead of travelling through memory to the next round.
+        // A lane leaves the loop in the pass that appends a trace item for it, or when its sample ends; scenes without models
+        // finish whole paths in round 0.  (What is combined, and in which order, is unchanged: only where the state waits.)
+        bool active = valid;
+#ifdef RTM_SHADE_TIMES
+        unsigned long long st_d = 0;
+#endif
+        for (uint32_t pass = 0;; ++pass) {  // (wave-uniform)
+        uint32_t h_obj = kNoId, h_mat = 0, h_tri = kNoId;  // slot 0's hit
+        double best0 = 0.0;
+        bool found0 = false;
+        if (pass > 0u) { cont = false; go0 = false; }
+        go1 = false; go2 = false;
+        if (active && (!ROUND0 || pass > 0u)) {
+            {
                 if (fl & FB_HELD) { r0.t = held_t; r0.tri = held_tri; r0.model = held_m; }  // slot 0's answer came in an earlier round
                 if (A.att_replay) {  // main.rs:118,124: the same multiplications in the same order as when the vertices were finished
                     att = 1.0;
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 }
                 // ---- 1. the path query: analytic hit, then the model hit the trace kernel found (core.rs:75-83)
                 if (b_take) {
-                    if (A.rehit) {  // the analytic part of the query again, from the ray the state holds
+                    if (A.rehit && !fresh0) {  // the analytic part of the query again, from the ray the state holds
                         double rb = __builtin_inf();
                         bool rf = false;
                         uint32_t ro = kNoId, rm = 0u, rk = 0u;
@@ -531,18 +546,13 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 fl &= a_more ? (FB_HASV | FB_FOUND0 | FB_TQ0 | FB_HELD) : FB_HASV;
             }
         }
-        // ---- the slot the path moves to (dense, in the other buffer)
-        const unsigned long long alive = __ballot(valid && cont);
-        const uint32_t p_out = sq * A.cap_l + n_live_local + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull));
-        n_live_local += (uint32_t)__popcll(alive);
-        auto stD = [&](int f, double v) { Dout[at64(PF_COUNT, f, p_out)] = v; };
-        auto stD3 = [&](int f, V3 v) { stD(f, v.x); stD(f + 1, v.y); stD(f + 2, v.z); };
-        auto stU = [&](int f, uint32_t v) { Uout[at64(PU_COUNT, f, p_out)] = v; };
-
         // ---- a query: analytic primitives (core.rs:183-210), slab test and DDA set-up of the first model whose box
         //      the ray meets (box3D.rs:64-93, core.rs:95-125); that model and the following ones are the trace kernel's
         // Shadow queries (j > 0) bring dl2 = |light - o|^2 and `lit`: a sphere or plane that occludes the light settles the
         // query here (its flag FB_C stays clear and no ray goes to the models, unless exact work counters are wanted).
+        // The item's path slot (IU_P) is written once the lane knows its next slot, below.
+        size_t it_of0 = 0, it_of1 = 0, it_of2 = 0;
+        bool item0 = false, item1 = false, item2 = false;
         auto issue = [&](const uint32_t j, const bool go, const V3 dir, const double dl2, const bool lit) __attribute__((always_inline)) {
             bool item = false;
             int ix = 0, iy = 0, iz = 0;
@@ -557,6 +567,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 if (j == 0u) {
                     ba0 = best;
                     h_kp = b_kp;
+                    fresh0 = true;
                     if (found) fl |= FB_FOUND0;
                 } else {
                     const bool occ = found && sqdist(ray_at(o, dir, best), o) <= dl2;
@@ -604,12 +615,12 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     if (j != 0u) { I[at64(IT_DCOUNT, IT_D + 0, it)] = dir.x; I[at64(IT_DCOUNT, IT_D + 1, it)] = dir.y; I[at64(IT_DCOUNT, IT_D + 2, it)] = dir.z; }
                     I[at64(IT_DCOUNT, IT_TM + 0, it)] = tmx; I[at64(IT_DCOUNT, IT_TM + 1, it)] = tmy; I[at64(IT_DCOUNT, IT_TM + 2, it)] = tmz;
                     A.itU[at64(IU_COUNT, IU_CELL, it)] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
-                    A.itU[at64(IU_COUNT, IU_P, it)] = p_out;  // the path's next slot: where the trace kernel finds the ray's origin
                     A.itU[at64(IU_COUNT, IU_M, it)] = mword;
+                    if (j == 0u) { it_of0 = it; item0 = true; } else if (j == 1u) { it_of1 = it; item1 = true; } else { it_of2 = it; item2 = true; }
                 }
             }
         };
-        issue(0u, go0, dir0, 0.0, false);
+        issue(0u, active && go0, dir0, 0.0, false);
         {
             // shadow rays to lights li, li+1 (main.rs:80-85) and what each would add to the diffuse sum (main.rs:96-102)
             auto shadow = [&](const uint32_t j, const bool go) __attribute__((always_inline)) {
@@ -628,23 +639,47 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 }
                 issue(1u + j, go && trace, dir, dl2, lit);  // (the host turns culling off when exact work counters are wanted)
             };
-            shadow(0u, go1);
-            shadow(1u, go2);
+            shadow(0u, active && go1);
+            shadow(1u, active && go2);
         }
+        fl = (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT);
+        // ---- who waits for the trace kernel, who goes round again in the lane
+        const bool pending = (fl & (FB_TQ1 | FB_TQ2)) != 0u || ((fl & FB_TQ0) != 0u && !(fl & FB_HELD));
+        // (... provided enough lanes of the wave do: a pass with a few lanes costs what a full one costs, and the paths that go
+        // through memory instead come back compacted)
+        const bool could = active && cont && !pending;
+        const bool again = could && (uint32_t)__popcll(__ballot(could)) >= A.inlane;
+        const bool keep = active && cont && !again;
+        // ---- the slot the path moves to (dense, in the other buffer)
+        const unsigned long long alive = __ballot(keep);
+        const uint32_t p_out = sq * A.cap_l + n_live_local + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull));
+        n_live_local += (uint32_t)__popcll(alive);
+        auto stD = [&](int f, double v) { Dout[at64(PF_COUNT, f, p_out)] = v; };
+        auto stD3 = [&](int f, V3 v) { stD(f, v.x); stD(f + 1, v.y); stD(f + 2, v.z); };
+        auto stU = [&](int f, uint32_t v) { Uout[at64(PU_COUNT, f, p_out)] = v; };
 #ifdef RTM_SHADE_TIMES
-        const unsigned long long st_d = __builtin_amdgcn_s_memtime();
+        st_d = __builtin_amdgcn_s_memtime();
 #endif
-        if (valid && cont) {  // the state moves on
+        if (keep) {  // the state moves on
+            // the path's next slot: where the trace kernel finds the origin of its rays
+            if (item0) A.itU[at64(IU_COUNT, IU_P, it_of0)] = p_out;
+            if (item1) A.itU[at64(IU_COUNT, IU_P, it_of1)] = p_out;
+            if (item2) A.itU[at64(IU_COUNT, IU_P, it_of2)] = p_out;
             stD3(PF_COL, col);
             if (!A.att_replay) stD(PF_ATT, att);
             stD3(PF_O, o); stD3(PF_D0, dir0);
             if (!A.rehit) stD(PF_BA0, ba0);
             stD(PF_EFF, eff0); stD(PF_EFF + 1, eff1);
             if (nL > 2u) { stD3(PF_NRM, nn); stD3(PF_DIFF, diff); stD(PF_HELD, held_t); stU(PU_HTRI, held_tri); stU(PU_HM, held_m); stU(PU_LI, li); }
-            stU(PU_FLB, (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT) | (bounce << FB_BOUNCE_SHIFT));
+            stU(PU_FLB, fl | (bounce << FB_BOUNCE_SHIFT));
             if (!A.rehit) stU(PU_HKP, h_kp);
             stU(PU_MAT, A.att_replay ? (mat | (hist << 16)) : mat);
             stU(PU_HOME, home);
+        }
+        active = again;
+        if (!__ballot(active)) break;
+        r0.t = 0.0; r0.tri = kNoId; r0.model = kNoId;  // later passes: nothing was traced for this lane
+        l_r1 = r0; l_r2 = r0;
         }
 #ifdef RTM_SHADE_TIMES
         {

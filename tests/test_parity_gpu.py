@@ -112,7 +112,8 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
     try:
         for key, value in (("front_max_paths", 64), ("front_max_paths", 26 * 64 * 3 * 4), ("front_cull", 0), ("front_refill", 1),
                            ("front_refill", 64), ("front_streams", 1), ("front_streams", 4), ("front_streams", 0), ("front_claim", 16), ("front_steal", 512),
-                           ("front_steal", 0), ("front_coop", 0), ("front_rehit", 0)):
+                           ("front_steal", 0), ("front_coop", 0), ("front_rehit", 0),
+                           ("front_inlane", 0), ("front_inlane", 1), ("front_inlane", 64)):
             rtm_gpu.set_tuning(key, value)
             g = s.render(spp=3, seed=4, width=203, height=77, stats=True)
             assert_frames_match(g, ref, f"suzanne {key}={value}")
@@ -128,6 +129,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("front_steal", 8)
         rtm_gpu.set_tuning("front_coop", 1)
         rtm_gpu.set_tuning("front_rehit", 1)
+        rtm_gpu.set_tuning("front_inlane", -1)
     with pytest.raises(rtm_gpu.RtmError):
         rtm_gpu.set_tuning("no_such_knob", 1)
 
@@ -375,6 +377,23 @@ def test_teapot_and_soup_scene(rtm_gpu, orc):
     assert_frames_match(g, c, "teapot+soup")
     assert g["counters"] == c["counters"]
     assert (g["obj_id"] == 1).any() and (g["obj_id"] == 2).any()
+
+
+@pytest.mark.parametrize("inlane", (0, 1, 40))
+def test_inlane_advance_does_not_change_bits(inlane, rtm_gpu, rtm_scene, oracle_scene):
+    """Paths whose queries are all settled by the analytic primitives advance inside the shade kernel's lane instead of
+    waiting a round (rtm_set_tuning("front_inlane", min lanes)): scenes without models then finish in round 0, with three
+    and four lights (several light batches per vertex) -- oracle bits and counters whatever the threshold."""
+    try:
+        rtm_gpu.set_tuning("front_inlane", inlane)
+        for name in ("simple_sphere", "multisphere", "bunny"):
+            ref = oracle_scene(name).render(spp=3, seed=13, width=150, height=90)
+            g = rtm_scene(name).render(spp=3, seed=13, width=150, height=90, stats=True)
+            assert_frames_match(g, ref, f"{name} inlane={inlane}")
+            assert g["counters"] == ref["counters"]
+            assert np.array_equal(rtm_scene(name).render(spp=3, seed=13, width=150, height=90)["rgb"], ref["rgb"])
+    finally:
+        rtm_gpu.set_tuning("front_inlane", -1)
 
 
 def test_pool_trace_kernel_gives_the_same_bits(rtm_gpu, rtm_scene, oracle_scene, orc):
