@@ -117,6 +117,9 @@ def main():
                     help="skip the extra pass with one chunk in flight (rocprofv3 runs: every launch of the process is then in the "
                          "regime of the timed steps, and the profiler's average kernel duration is comparable with roofline.kernel_ms)")
     ap.add_argument("--streams", type=int, default=2, help="chunks of a frame in flight at once (rtm_set_tuning front_streams; default 2, 0 = by frame size)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the gather + de-interleave of the N > 1 step even with one rank "
+                         "(rehearsal of the multi-GPU control flow on a one-GPU box; launch under torch.distributed.run)")
     ap.add_argument("--gather", choices=("f64", "u8"), default="f64",
                     help="N > 1: what rank 0 collects -- the f64 framebuffer (default, the parity path) or the 8-bit image "
                          "after the device tonemap (main.rs:173-185; an eighth of the bytes)")
@@ -137,8 +140,10 @@ def main():
     torch.cuda.set_device(local_rank)
     rtm.init(local_rank)
     rtm.set_tuning("front_streams", args.streams)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if args.workload == "soup":
@@ -161,16 +166,16 @@ def main():
 
     def step():
         scene.render_device(p_local, local.data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
+        if use_dist:
             # one gather of the compact row blocks to rank 0 over xGMI (RCCL), then de-interleave
             if local8 is not None:
                 rtm.tonemap_device(local.data_ptr(), rows * W, False, local8.data_ptr(), stream=stream.cuda_stream)
-                gather_frame(local8, H, W, rank, world, scratch=scratch)
-            else:
-                gather_frame(local, H, W, rank, world, deinterleave_device=rtm.deinterleave_device, scratch=scratch)
+                return gather_frame(local8, H, W, rank, world, scratch=scratch, force=use_dist)
+            return gather_frame(local, H, W, rank, world, deinterleave_device=rtm.deinterleave_device, scratch=scratch, force=use_dist)
+        return local
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -181,7 +186,7 @@ def main():
     progress(f"{args.workload} {W}x{H} at {args.spp} spp: counting frame")
     # exact ray / work counts of the whole frame (outside the timed region)
     cnt = scene.render_device(p_local, local.data_ptr(), stats=True, stream=stream.cuda_stream)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([cnt[k] for k in rtm.STAT_NAMES], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
         cnt = dict(zip(rtm.STAT_NAMES, (int(v) for v in t.tolist())))
@@ -197,7 +202,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     progress(f"{dt / args.steps * 1e3:.2f} ms per step; timing the dominant kernel")
-    if world > 1:
+    n_ranks_seen = 1
+    if use_dist:
+        one = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(one)  # the ranks RCCL actually connects: must equal n_gpus
+        n_ranks_seen = int(one.item())
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -236,23 +245,44 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = rays * args.steps / dt / 1e6
-        # SURVEY 8(d) per-unit figures x the units the trace kernel processed: 48 B ray + 40 B result per traced ray,
-        # 8 B per cell visited, 76 B per triangle test
+        # SURVEY 8(d) per-unit figures x the units the dominant kernel processed.  Scenes with models: the trace kernel (48 B ray
+        # + 40 B result per traced ray, 8 B per cell visited, 76 B per triangle test).  Scenes whose time is in the shade kernel
+        # (no models, or few rays that reach them): its queries -- 88 B per ray issued, 32 B per sphere or plane test, 48 B per
+        # model-box test -- plus the 24 B/pixel framebuffer.
         # (per launch in the regime of the timed frames: two chunks in flight make twice as many launches of half the size)
-        n_launch = max(1, ev_n // args.steps if ev_n else prof["trace_launches"])
-        n_launch_iso = max(1, iso_n // iso_steps if iso_n else prof["trace_launches"])
-        frame_bytes = 88.0 * prof["traced_rays"] + 8.0 * prof["cells_visited"] + 76.0 * prof["tri_tests"]
+        single = prof["shade_launches"] == 0
+        shade_dominant = (not single) and prof["shade_ms"] > prof["trace_ms"]
+        if shade_dominant:
+            # timed by rtm_profile_render_device: a HIP event pair around every launch, on the stream it is launched on, one
+            # chunk of the frame in flight at a time (the shade launches of ordinary frames carry no events)
+            n_launch = n_launch_iso = max(1, prof["shade_launches"])
+            frame_bytes = (88.0 * prof["rays_total"] + 32.0 * (prof["sphere_tests"] + prof["plane_tests"]) + 48.0 * prof["bbox_tests"] + 24.0 * W * rows)
+            kern_ms = kern_ms_iso = prof["shade_ms"] / n_launch
+            flops = (25.0 * prof["sphere_tests"] + 17.0 * prof["plane_tests"] + 31.0 * prof["bbox_tests"]) / n_launch
+            ev_n_out, iso_n_out = prof["shade_launches"], prof["shade_launches"]
+            iso_frame = prof["total_ms"]
+        else:
+            n_launch = max(1, ev_n // args.steps if ev_n else prof["trace_launches"])
+            n_launch_iso = max(1, iso_n // iso_steps if iso_n else prof["trace_launches"])
+            frame_bytes = 88.0 * prof["traced_rays"] + 8.0 * prof["cells_visited"] + 76.0 * prof["tri_tests"]
+            kern_ms = ev_ms / ev_n if ev_n else prof["trace_ms"] / n_launch  # (single-kernel formulations record no events)
+            kern_ms_iso = iso_ms / iso_n if iso_n else kern_ms
+            flops = (9.0 * prof["cells_visited"] + 41.0 * prof["tri_tests"]) / n_launch
+            ev_n_out, iso_n_out = ev_n, iso_n
+            iso_frame = iso_frame_ms
         abytes = frame_bytes / n_launch
-        kern_ms = ev_ms / ev_n if ev_n else prof["trace_ms"] / n_launch  # (single-kernel formulations record no events)
-        kern_ms_iso = iso_ms / iso_n if iso_n else kern_ms
         achieved = abytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(f"{args.workload}_{W}x{H}_{args.spp}spp_n{world}", {}).get("hbm_bytes_per_launch")
-        flops = (9.0 * prof["cells_visited"] + 41.0 * prof["tri_tests"]) / n_launch
-        single = prof["shade_launches"] == 0
         headline = args.workload == "bunny" and W == 1200 and args.spp == 20
+        if single:
+            kname = "rtw::render_wave_kernel<false>"
+        elif shade_dominant:
+            kname = "rtf::front_shade_kernel<false, *, true> (all rounds)"
+        else:
+            kname = "rtf::front_trace_kernel<false, true, true>" if args.workload == "soup" else "rtf::front_trace_kernel<false, true, false>"
         out = {
             "metric": "Mrays/s (primary+shadow) bunny 1200^2 20spp" if headline
             else f"Mrays/s (primary+shadow) {args.workload} {W}x{H} {args.spp}spp",
@@ -269,19 +299,24 @@ def main():
                                     "the oracle's). The device path answers shadow rays whose light is behind the surface (main.rs:96 "
                                     "fails) without tracing them: rays_issued is what it does issue, and of those only the rays that "
                                     "enter a model's box reach the trace kernel: rays_traced (both on this rank)",
-                       "front_streams": args.streams or "by frame size (3 chunks in flight from 12 Mi sample paths per frame, else 2)", "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if world > 1 else "")},
+                       "n_ranks": n_ranks_seen, "process_group": ("nccl (RCCL), %d rank(s)" % dist.get_world_size()) if use_dist else None,
+                       "front_streams": args.streams or "by frame size (3 chunks in flight from 12 Mi sample paths per frame, else 2)", "parallelism": f"row-interleave x{world}" + (f" + RCCL gather ({args.gather}) to rank 0" if use_dist else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rtw::render_wave_kernel<false>" if single else
-                         ("rtf::front_trace_kernel<false, true, true>" if args.workload == "soup" else "rtf::front_trace_kernel<false, true, false>"),
-                         "bytes_are": "algorithmic (SURVEY 8d: 88 B per traced ray + 8 B per cell + 76 B per triangle test), not measured; "
-                                      "`traffic` is the measured HBM figure",
-                         "kernel_ms": kern_ms, "kernel_launches_timed": ev_n, "launches_per_frame": n_launch,
-                         "kernel_ms_isolated": kern_ms_iso if iso_n else None, "isolated_launches_timed": iso_n, "isolated_frame_ms": iso_frame_ms,
-                         "frac_isolated": frame_bytes / n_launch_iso / (kern_ms_iso * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_n else None,
-                         "launches_per_frame_isolated": n_launch_iso if iso_n else None,
+                         "traffic": traffic, "kernel": kname,
+                         "bytes_are": "algorithmic (SURVEY 8d), not measured: " + ("88 B per ray issued + 32 B per sphere or plane test + 48 B per model-box test + 24 B per pixel"
+                                      if shade_dominant else "88 B per traced ray + 8 B per cell + 76 B per triangle test") +
+                                      "; `traffic` is the measured HBM figure per launch and frac_measured_traffic what it comes to",
+                         "frac_measured_traffic": (traffic / (kern_ms_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "kernel_ms": kern_ms, "kernel_launches_timed": ev_n_out, "launches_per_frame": n_launch,
+                         "kernel_ms_isolated": kern_ms_iso if iso_n_out else None, "isolated_launches_timed": iso_n_out, "isolated_frame_ms": iso_frame,
+                         "frac_isolated": frame_bytes / n_launch_iso / (kern_ms_iso * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_n_out else None,
+                         "launches_per_frame_isolated": n_launch_iso if iso_n_out else None,
                          "algorithmic_bytes_per_launch": abytes,
-                         "binding_limit": "VALU issue (f64 triangle tests, f32 box screen) and vector-memory latency of per-lane gathers: "
-                                          "the scene and the queues of a round are L2/MALL-resident, see valu and DESIGN.md"},
+                         "limiter": "valu-issue",
+                         "binding_limit": ("FP64 VALU issue of the analytic primitives (sphere discriminants, plane tests: wave-uniform operands, every lane busy) and the "
+                                           "streamed path state; the scene is L2-resident, see valu" if shade_dominant else
+                                           "VALU issue (f64 triangle tests, f32 box screen) at ~35 of 64 lanes and vector-memory latency of per-lane gathers: "
+                                           "the scene and the queues of a round are L2/MALL-resident (measured traffic is a fraction of the algorithmic bytes), see valu and DESIGN.md")},
             "valu": {"achieved_tflops": flops / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
                      "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "algorithmic_flops_per_launch": flops},
             "pipeline": {"frame_ms": frame_ms, "one_chunk_at_a_time": (not args.no_isolated) or args.streams == 1, "shade_ms": prof["shade_ms"], "trace_ms": prof["trace_ms"],
@@ -293,7 +328,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, W, H, args.soup_tris)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

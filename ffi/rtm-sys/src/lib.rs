@@ -129,6 +129,9 @@ pub struct rtm_profile {
     pub cells_visited: u64,
     pub tri_tests: u64,
     pub rays_total: u64,
+    pub sphere_tests: u64,
+    pub plane_tests: u64,
+    pub bbox_tests: u64,
 }
 
 /// Opaque: the C++ stand-in front end (not needed from Rust, which has its own parser; declared for completeness).
@@ -153,6 +156,7 @@ extern "C" {
     pub fn rtm_render_device_noalloc(scene: *const rtm_scene_dev, params: *const rtm_params, d_rgb: *mut f64,
                                      d_obj_id: *mut u32, d_tri_id: *mut u32, stream: *mut c_void) -> c_int;
     pub fn rtm_noalloc_scratch_bytes() -> u64;
+    pub fn rtm_front_scene_fits(list_entries: u64, cells: u64) -> c_int;
     pub fn rtm_time_render_device(scene: *const rtm_scene_dev, params: *const rtm_params, d_rgb: *mut f64, iters: c_int,
                                   stream: *mut c_void, out_ms_avg: *mut f64) -> c_int;
     pub fn rtm_profile_render_device(scene: *const rtm_scene_dev, params: *const rtm_params, d_rgb: *mut f64,

@@ -115,6 +115,12 @@ typedef struct rtm_scene_dev rtm_scene_dev; /* opaque: a scene resident in HBM *
 /* Number of rows a params block renders: ceil((height-row_begin)/row_stride). */
 uint32_t rtm_local_rows(const rtm_params* p);
 
+/* Whether a scene with `list_entries` grid-list entries and `cells` grid cells (padded to 32 per model) over all its models
+ * fits the packed indices of the ray-front pipeline (1) or is rendered by the single-kernel formulation (0).  Host arithmetic
+ * only, no device needed; no counterpart in the reference.  Limits: 429 496 729 entries (a list position times ten is formed
+ * in 32 bits), 2^27 cells. */
+int rtm_front_scene_fits(uint64_t list_entries, uint64_t cells);
+
 /* Select the HIP device of this process (one process per GPU).  device < 0: use LOCAL_RANK or 0.
  * Calling it again with another device releases what the library held on the old one (work space, streams, events);
  * free the scenes uploaded there first.  No counterpart in the reference (it has no device). */
@@ -136,7 +142,13 @@ const char* rtm_version(void);
  *                      their cells' entries for them,
  *   "front_rehit"      1 (default): in scenes with at most four spheres and planes the analytic hit of a path query is
  *                      computed again when its answer is taken instead of travelling with the path (12 bytes per path and round),
- *                      and for up to 16 bounces the attenuation is multiplied up again from the vertices' metal flags (8 bytes).
+ *                      and for up to 16 bounces the attenuation is multiplied up again from the vertices' metal flags (8 bytes),
+ *   "front_inlane"     a path whose bounce and shadow queries all missed the models' boxes advances to its next vertex inside
+ *                      the shade kernel's lane when at least this many lanes of the wave do (1..64, default 24; 0 = never: every
+ *                      vertex waits a round; -1 = default).  Unless set by hand it is off in scenes with more than 16 spheres and planes,
+ *   "front_pool"       1: the trace kernel parks a pool of 96 rays per wave in LDS and runs every walk / test step on up to 64
+ *                      rays that are ready for it (rt_pool.h); 0 (default): one ray per lane, in registers.  Measured slower
+ *                      (DESIGN.md 4.2), kept as a cross-check; "pool_refill", "pool_walk_more", "pool_test_frac" tune it.
  * Returns RTM_ERR_INVALID for an unknown key or a value out of range.  The same knobs are read from the
  * environment (RTM_FRONT_MAX_PATHS, ...) by rtm_init. */
 int rtm_set_tuning(const char* key, long long value);
@@ -188,6 +200,7 @@ typedef struct rtm_profile {
     uint64_t traced_rays;                   /* rays that entered a model's box and went through the trace kernel */
     uint64_t cells_visited, tri_tests;      /* work of the trace kernel */
     uint64_t rays_total;                    /* camera + bounce + shadow rays issued (culled shadow rays not counted) */
+    uint64_t sphere_tests, plane_tests, bbox_tests;  /* work of the shade kernel's queries (culled shadow rays make none) */
 } rtm_profile;
 int rtm_profile_render_device(const rtm_scene_dev* scene, const rtm_params* params, double* d_rgb, void* stream,
                               rtm_profile* out);
@@ -205,15 +218,18 @@ int rtm_trace_rays(const rtm_scene_dev* scene, uint64_t n, const double* rays6, 
 
 /* Framebuffer -> 8-bit RGB with the reference's rule (main.rs:33-48,176-185): optional gamma
  * c>0 ? c^(1/2.2) : 0, then (c*255.0) saturating-truncating cast.  d_rgb, d_rgb8: device pointers.
- * Without gamma the bytes are exactly the reference's.  With gamma the power is the device's pow(), the reference's is
- * the host libm's powf: a value that lands within an ulp of a multiple of 1/255 can come out one code value apart, so the
- * gamma path (here, in rtm_render_rgb8 and in rtm_cli_main --gamma-correction) is NOT bit-pinned: at most +-1 per byte. */
+ * Without gamma the bytes are exactly the reference's.  With gamma the power is the DEVICE's pow(), the reference's is
+ * the host libm's (f64::powf): a value that lands within an ulp of a multiple of 1/255 can come out one code value apart, so
+ * this entry point's gamma path is at most +-1 per byte.  rtm_render_rgb8 and rtm_cli_main --gamma-correction do not use it:
+ * they apply the gamma on the host and give the reference's bytes. */
 int rtm_tonemap_device(const double* d_rgb, uint64_t n_pixels, int gamma, uint8_t* d_rgb8, void* stream);
 
 /* main.rs:153-185 in one call for callers that only want the 8-bit image: renders like
- * rtm_render_device, converts on the device with rtm_tonemap_device's rule and copies local_rows*width*3 bytes to the
- * HOST buffer out_rgb8 -- an eighth of the f64 framebuffer over PCIe.  out_seconds (may be NULL): wall time of
- * render + conversion + copy, the bracket of main.rs:156-187.  Synchronous. */
+ * rtm_render_device, then (gamma == 0) converts on the device with rtm_tonemap_device's rule and copies local_rows*width*3
+ * bytes to the HOST buffer out_rgb8 -- an eighth of the f64 framebuffer over PCIe -- or (gamma != 0) copies the f64
+ * framebuffer to the host and applies main.rs:42-48 there with the host libm's pow, as the reference does (main.rs:179-183):
+ * in both cases the bytes are the reference's.  out_seconds (may be NULL): wall time of render + conversion + copy, the
+ * bracket of main.rs:156-187.  Synchronous. */
 int rtm_render_rgb8(const rtm_scene_dev* scene, const rtm_params* params, int gamma, uint8_t* out_rgb8,
                     double* out_seconds);
 
@@ -253,7 +269,9 @@ int rtm_frontend_free(rtm_frontend* fe);
  * tri_idx_capacity is smaller (or the tri_idx pointer NULL) the offsets are still written and the call returns
  * RTM_ERR_INVALID: allocate that many and call again.  cells_per_side 1..128 (the reference uses 32, core.rs:62).
  * rtm_grid_build: host pointers in and out.  rtm_grid_build_device: d_pos[9], d_offsets, d_tri_idx are device pointers
- * (the array d_pos itself is a host array of nine device pointers); synchronises `stream`. */
+ * (the array d_pos itself is a host array of nine device pointers); it makes three temporary device allocations (cell ranges
+ * per triangle, counts and positions per (cell, segment): freed before it returns) and synchronises `stream` twice (the list
+ * total comes back to the host before the lists are written).  Needs rtm_init (RTM_ERR_STATE otherwise). */
 int rtm_grid_build(const double* const pos[9], uint32_t n_tris, const double bbox_center[3], const double bbox_half[3],
                    uint32_t cells_per_side, uint32_t* out_offsets, uint32_t* out_tri_idx, uint64_t tri_idx_capacity,
                    uint64_t* out_n_tri_idx);

@@ -41,7 +41,8 @@ if not os.path.exists(LIB_PATH):
 class RtmProfile(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("shade_ms", C.c_double), ("trace_ms", C.c_double), ("resolve_ms", C.c_double),
                 ("shade_launches", C.c_uint32), ("trace_launches", C.c_uint32), ("traced_rays", C.c_uint64),
-                ("cells_visited", C.c_uint64), ("tri_tests", C.c_uint64), ("rays_total", C.c_uint64)]
+                ("cells_visited", C.c_uint64), ("tri_tests", C.c_uint64), ("rays_total", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64), ("bbox_tests", C.c_uint64)]
 
 
 class RtmError(RuntimeError):
@@ -128,7 +129,7 @@ EXPORTED_SYMBOLS = (
     "rtm_scene_free", "rtm_render_device", "rtm_time_render_device", "rtm_profile_render_device", "rtm_trace_rays", "rtm_tonemap_device",
     "rtm_deinterleave_device", "rtm_f64_ops_selftest", "rtm_frontend_load", "rtm_frontend_add_triangles", "rtm_frontend_scene",
     "rtm_frontend_size", "rtm_frontend_free", "rtm_render_rgb8", "rtm_write_bmp", "rtm_cli_main", "rtm_timed_events_collect",
-    "rtm_render_device_noalloc", "rtm_noalloc_scratch_bytes", "rtm_grid_build", "rtm_grid_build_device")
+    "rtm_render_device_noalloc", "rtm_noalloc_scratch_bytes", "rtm_grid_build", "rtm_grid_build_device", "rtm_front_scene_fits")
 
 
 def raw_lib() -> C.CDLL:
@@ -179,6 +180,15 @@ def make_params(width: int, height: int, spp: int = 1, seed: int = 0, max_bounce
                 row_stride: int = 1, zero_jitter: bool = False, kernel_v1: bool = False, kernel_wave: bool = False) -> RtmParams:
     flags = (FLAG_ZERO_JITTER if zero_jitter else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_WAVE if kernel_wave else 0)
     return RtmParams(width, height, spp, max_bounces, seed, row_begin, row_stride, flags, 0)
+
+
+_lib.rtm_front_scene_fits.restype = C.c_int
+_lib.rtm_front_scene_fits.argtypes = [C.c_uint64, C.c_uint64]
+
+
+def front_scene_fits(list_entries: int, cells: int) -> bool:
+    """Whether a scene of that size runs the ray-front pipeline (host arithmetic only)."""
+    return bool(_lib.rtm_front_scene_fits(list_entries, cells))
 
 
 def local_rows(p: RtmParams) -> int:

@@ -151,8 +151,7 @@ int rtm_grid_build_device(const double* const d_pos[9], uint32_t n_tris, const d
         return rtm_internal_fail(RTM_ERR_INVALID, "rtm_grid_build_device: cells_per_side must be 1..128 (the reference uses 32)");
     for (int a = 0; a < 9; ++a)
         if (n_tris && !d_pos[a]) return rtm_internal_fail(RTM_ERR_INVALID, "triangle arrays missing");
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return rtm_internal_fail(RTM_ERR_STATE, "rtm_init has not been called");
+    if (rtm_internal_device() < 0) return rtm_internal_fail(RTM_ERR_STATE, "rtm_init has not been called");
     hipStream_t stream = (hipStream_t)stream_;
     GridArgs A{};
     const double n = (double)cells_per_side;

@@ -35,6 +35,7 @@ int rtm_internal_fail(int code, const std::string& msg) {
     } while (0)
 
 static int g_device = -1;
+int rtm_internal_device() { return g_device; }
 static uint32_t* g_work_counter = nullptr;  // device word: next unclaimed tile of the frame in flight (rt_wave.h)
 static int g_num_cus = 256;
 static uint32_t g_t_test_frac = 44;  // env RTM_TEST_FRAC
@@ -292,6 +293,12 @@ int need_init() {
 
 extern "C" {
 
+// The packed indices of the ray-front path (rt_front.h): a list position times ten (doubles per record) is formed in 32 bits,
+// and a scene cell number shares a word with three bits of arrival code.  Scenes beyond either run the single-kernel formulation.
+int rtm_front_scene_fits(uint64_t list_entries, uint64_t cells) {
+    return list_entries <= (uint64_t)rtf::kMaxListEntries && cells < (1ull << 27) ? 1 : 0;
+}
+
 uint32_t rtm_local_rows(const rtm_params* p) {
     if (!p || p->row_stride == 0 || p->row_begin >= p->height) return 0;
     return (p->height - p->row_begin + p->row_stride - 1) / p->row_stride;
@@ -506,7 +513,7 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
         // the lists again, as records in list order (rt_front.h): a cell's entries are contiguous 80-byte records, so the
         // traversal reads them without the indirection through tri_idx and neighbouring entries share cache lines
         const uint64_t entry_base = g_rec.size() / 10, cell_base = total_cells;
-        if (entry_base + M.n_tri_idx >= 0xFFFFFFF0ull || cell_base + n3 >= (1ull << 27)) {
+        if (!rtm_front_scene_fits(entry_base + M.n_tri_idx, cell_base + n3)) {
             sd->front_ok = false;  // (beyond the packed indices of rt_front.h: the single-kernel formulation renders such scenes)
         }
         D.cell_base = (uint32_t)cell_base;
@@ -723,9 +730,28 @@ FrontLayout front_layout(size_t np_max, uint32_t nq) {
     return L;
 }
 
+int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, uint32_t occ_words, double* d_rgb, uint32_t* d_obj,
+                       uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof, const FrontFixedWs* fixed);
+
+// An error in the middle of a frame (a failed launch, an event that cannot be recorded) leaves kernels queued on the internal
+// streams with nothing ordering the caller's stream, or the next frame's work space, after them: wait for them before the error
+// is reported, so that the caller may free or reuse its outputs.
 int render_front(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, uint32_t occ_words, double* d_rgb, uint32_t* d_obj,
                  uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof = nullptr,
                  const FrontFixedWs* fixed = nullptr) {
+    const int rc = render_front_queue(sd, p, n_rows, occ_words, d_rgb, d_obj, d_tri, d_cnt, stream, prof, fixed);
+    if (rc != RTM_OK && !fixed) {
+        const std::string msg = g_last_error;
+        for (int i = 0; i < kFrontStreamsMax; ++i)
+            if (g_front_stream[i]) (void)hipStreamSynchronize(g_front_stream[i]);
+        (void)hipStreamSynchronize(stream);
+        g_last_error = msg;
+    }
+    return rc;
+}
+
+int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_rows, uint32_t occ_words, double* d_rgb, uint32_t* d_obj,
+                       uint32_t* d_tri, unsigned long long* d_cnt, hipStream_t stream, FrontProfile* prof, const FrontFixedWs* fixed) {
     const bool stats = d_cnt != nullptr;
     int mark_rc = RTM_OK;
     auto mark = [&](int kind, bool end, hipStream_t on) {  // event before / after a launch (profile runs only)
@@ -1180,7 +1206,7 @@ int rtm_render_device_noalloc(const rtm_scene_dev* sd, const rtm_params* p, doub
     if (!sd || !d_rgb) return rtm_internal_fail(RTM_ERR_INVALID, "scene or output is null");
     if (int rc = check_params(p)) return rc;
     if (p->flags & (RTM_FLAG_KERNEL_V1 | RTM_FLAG_KERNEL_WAVE)) return rtm_internal_fail(RTM_ERR_INVALID, "rtm_render_device_noalloc runs the ray-front pipeline only");
-    if (!front_supported(sd, p)) return rtm_internal_fail(RTM_ERR_INVALID, "scene or frame beyond the ray-front pipeline's limits (grid > 1023 cells per side, >= 2^26 list entries)");
+    if (!front_supported(sd, p)) return rtm_internal_fail(RTM_ERR_INVALID, "scene or frame beyond the ray-front pipeline's limits (grid > 512 cells per side, > 429 496 729 list entries or >= 2^27 cells over all models, > 65 535 bounces)");
     if (sd->device != g_device || !g_scratch_ptr[g_device]) return rtm_internal_fail(RTM_ERR_STATE, "scene was uploaded to another device, or rtm_init has not bound the scratch array");
     if (g_render_busy.exchange(true)) return rtm_internal_fail(RTM_ERR_STATE, "another thread is inside a render call (the library is not re-entrant)");
     const FrontFixedWs ws{g_scratch_ptr[g_device], kStaticScratchBytes};
@@ -1231,6 +1257,7 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
         out->cells_visited = st.cells_visited; out->tri_tests = st.tri_tests;
         out->rays_total = st.rays_camera + st.rays_bounce + st.rays_shadow;
         out->traced_rays = st.bbox_tests;
+        out->sphere_tests = st.sphere_tests; out->plane_tests = st.plane_tests; out->bbox_tests = st.bbox_tests;
         return RTM_OK;
     }
     const uint32_t occ_words = front_occ_words(sd);
@@ -1276,6 +1303,7 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
         out->cells_visited = h[6];
         out->tri_tests = h[7];
         out->traced_rays = h[32];
+        out->sphere_tests = h[3]; out->plane_tests = h[4]; out->bbox_tests = h[5];
     }
     (void)hipFree(d_buf);
     if (rc != RTM_OK) return rc;
@@ -1413,12 +1441,27 @@ int rtm_render_rgb8(const rtm_scene_dev* sd, const rtm_params* p, int gamma, uin
         (void)hipFree(d_rgb);
         return rtm_internal_fail(RTM_ERR_DEVICE, "rtm_render_rgb8: out of device memory");
     }
-    // the bracket of main.rs:156-187: render, then the conversion to 8 bits (here on the device), image in host memory
+    // the bracket of main.rs:156-187: render, then the conversion to 8 bits, image in host memory.  Without gamma the
+    // conversion runs on the device (3 bytes per pixel cross PCIe).  With gamma the f64 framebuffer comes to the host and
+    // value.powf(1.0 / 2.2) (main.rs:42-48) is the host libm's pow -- what Rust's f64::powf calls -- so the bytes are the
+    // reference's; the device's pow() may differ from it in the last place, which flips a code value now and then.
     const auto t0 = std::chrono::steady_clock::now();
     int rc = rtm_render_device(sd, p, d_rgb, nullptr, nullptr, nullptr, nullptr);
-    if (rc == RTM_OK) rc = rtm_tonemap_device(d_rgb, n_px, gamma, d_rgb8, nullptr);
     hipError_t e = hipSuccess;
-    if (rc == RTM_OK) e = hipMemcpy(out_rgb8, d_rgb8, n_px * 3, hipMemcpyDeviceToHost);
+    if (rc == RTM_OK && gamma) {
+        std::vector<double> host(n_px * 3);
+        e = hipMemcpy(host.data(), d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (size_t i = 0; i < n_px * 3; ++i) {
+                double v = host[i];
+                v = v > 0.0 ? std::pow(v, 1.0 / 2.2) : 0.0;
+                v = v * 255.0;
+                out_rgb8[i] = !(v > 0.0) ? 0 : (v >= 255.0 ? 255 : (uint8_t)v);  // (c*255.0) as u8: truncating, saturating, NaN -> 0
+            }
+    } else if (rc == RTM_OK) {
+        rc = rtm_tonemap_device(d_rgb, n_px, 0, d_rgb8, nullptr);
+        if (rc == RTM_OK) e = hipMemcpy(out_rgb8, d_rgb8, n_px * 3, hipMemcpyDeviceToHost);
+    }
     if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     (void)hipFree(d_rgb);
     (void)hipFree(d_rgb8);

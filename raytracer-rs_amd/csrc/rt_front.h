@@ -38,7 +38,7 @@ using namespace rtd;
 #endif
 
 constexpr int kBlock = 256;
-constexpr uint32_t kMaxListEntries = 1u << 26;    // list positions are multiplied by 10 in 32 bits
+constexpr uint32_t kMaxListEntries = 0xFFFFFFFFu / 10u;  // list positions over all models: a position times 10 (doubles per record) is formed in 32 bits
 constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256, kShadeSpheres = 256, kShadePlanes = 64;  // table sizes the shade kernel keeps in LDS
 constexpr size_t kShadeLdsBytes = (size_t)(kShadeLights * 8 + kShadeMats * 4) * 8 + (size_t)(kShadeModels + kShadeSpheres + kShadePlanes) * 2 * 4;
 constexpr int kModelTab = 256;               // models whose grid word the trace kernel keeps in LDS
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                         const unsigned long long wants = __ballot((uint32_t)j < cntw);
                         if (j >= 2 && !wants) continue;
                         if (STATS) { dg_slots++; dg_slot_lanes += (uint64_t)__popcll(wants); }
-                        const gptr<double> tp = cell_rec + (uint32_t)(ti[j] * 10u);  // fewer than 2^26 entries (kMaxListEntries)
+                        const gptr<double> tp = cell_rec + (uint32_t)(ti[j] * 10u);  // (at most kMaxListEntries positions: the product fits 32 bits)
                         const V3 v0 = ld3(tp), e1 = ld3(tp + 3), e2 = ld3(tp + 6);
                         ti[j] = (uint32_t)__double_as_longlong(tp[9]);  // the record ends with the triangle's index
                         const V3 pv = cross(d, e2);

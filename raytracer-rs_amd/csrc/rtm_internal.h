@@ -5,6 +5,8 @@
 
 // Records `msg` as the thread's last error (rtm_last_error) and returns `code`.
 int rtm_internal_fail(int code, const std::string& msg);
+// The device rtm_init selected for this process, or -1 before rtm_init / after rtm_shutdown (render.hip).
+int rtm_internal_device();
 
 // ---- device-resident scene ---------------------------------------------------------------------
 // Layout in HBM (DESIGN.md "Data layout"): analytic primitives and tables are small AoS records read

@@ -16,12 +16,13 @@ def rows_of_rank(height: int, rank: int, world: int) -> int:
 
 
 def gather_frame(local_rows: torch.Tensor, height: int, width: int, rank: int, world: int, deinterleave_device=None,
-                 scratch: dict | None = None):
+                 scratch: dict | None = None, force: bool = False):
     """local_rows: [rows_of_rank, width, 3] on this rank's device -- f64 (the parity path) or u8 after
     rtm_tonemap_device (an eighth of the bytes when only the bitmap is wanted, main.rs:173-185).
     Returns the [height, width, 3] frame on rank 0 and None elsewhere.  `scratch` (optional dict) keeps the
-    gather/frame buffers between frames."""
-    if world == 1:
+    gather/frame buffers between frames.  `force`: run the gather and the de-interleave even in a process group of one
+    rank (bench.py --force-dist: the N > 1 control flow on the one GPU a test box has)."""
+    if world == 1 and not force:
         return local_rows
     max_rows = rows_of_rank(height, 0, world)
     pad = local_rows

@@ -134,3 +134,15 @@ def test_render_without_gpu_fails_loudly(rtm):
     s = rtm.Scene(text="size 8 8\nsphere (0,0,3) 1 white")
     with pytest.raises(rtm.RtmError):
         s.render(spp=1)
+
+
+def test_front_scene_limits_guard(rtm):
+    """the ray-front path forms `list position * 10` in 32 bits, so scenes are routed to it only up to
+    0xFFFFFFFF // 10 list entries over all models (and below 2^27 grid cells); host arithmetic, no device."""
+    lim = 0xFFFFFFFF // 10
+    assert lim * 10 <= 0xFFFFFFFF < (lim + 1) * 10
+    fits = rtm.front_scene_fits
+    assert fits(0, 0) and fits(44343, 32768) and fits(lim, 1 << 20)
+    assert not fits(lim + 1, 32768)           # the product would wrap
+    assert not fits(1 << 32, 32768) and not fits(0xFFFFFFF0, 32768)  # (the old bound let these through)
+    assert fits(1000, (1 << 27) - 1) and not fits(1000, 1 << 27)

@@ -41,7 +41,7 @@ def _worker(rank, world, port, height, width, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height", [(2, 48), (3, 50)])
+@pytest.mark.parametrize("world,height", [(2, 48), (3, 50), (8, 64)])
 def test_row_interleave_gather_gloo(world, height, tmp_path):
     out = str(tmp_path / "ok.npy")
     port = 29500 + (os.getpid() % 2000) + world

@@ -252,10 +252,10 @@ def test_two_caller_streams_do_not_corrupt_each_other(rtm_gpu, rtm_scene):
     pa, pb = rtm_gpu.make_params(96, 64, spp=4, seed=2), rtm_gpu.make_params(320, 200, spp=6, seed=3)
     ref_a = s.render(spp=4, seed=2, width=96, height=64)["rgb"]
     ref_b = t.render(spp=6, seed=3, width=320, height=200)["rgb"]
+    for rel in (s, t):  # (scenes are freed before the library lets go of the device, as the header asks)
+        rel.release_device()
     rtm_gpu.shutdown()  # drop the work space so that the frames below have to grow it
     rtm_gpu.init(0)
-    for rel in (s, t):
-        rel.release_device()
     try:
         for streams in (1, 2):
             rtm_gpu.set_tuning("front_streams", streams)

@@ -46,3 +46,23 @@ def test_rccl_gather_then_deinterleave_on_one_stream(rtm_gpu, rtm_scene):
         assert torch.equal(out8[0], rgb8)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_step_under_torchrun_with_a_process_group(rtm_gpu):
+    """bench.py's own N > 1 step -- render, RCCL gather of the row blocks, de-interleave, barrier and max-over-ranks timing --
+    launched the way the driver launches it (torch.distributed.run starts before anything touches the GPU), with the one rank
+    a one-GPU box allows (--force-dist): the first execution of that control flow must not be the driver's 8-GPU run."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29700 + os.getpid() % 2000
+    for gather in ("f64", "u8"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-dist",
+               "--spp", "2", "--size", "256", "--no-cpu-baseline", "--no-isolated", "--gather", gather]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["config"]["n_ranks"] == 1 and "RCCL" in line["config"]["process_group"]
+        assert line["value"] > 0 and "RCCL gather (%s)" % gather in line["config"]["parallelism"]
