@@ -130,7 +130,8 @@ const char* rtm_last_error(void);
 /* Library version string and the gfx target it was compiled for. */
 const char* rtm_version(void);
 /* Scheduling knobs of the device path (no effect on results; no counterpart in the reference).  Keys:
- *   "front_max_paths"  sample paths kept in flight per band of rows (workspace: ~700 B each; default 32 Mi),
+ *   "front_max_paths"  sample paths in flight at once over the chunks of a frame (work space: ~0.5 KB each); 0 (default) = by frame
+ *                      size: chunks of 4 Mi to 64 Mi paths, two rounds of "front_streams" chunks where the frame allows,
  *   "front_cull"       1 (default): shadow rays whose light is behind the surface (main.rs:96 fails) are not traced,
  *   "front_refill"     idle lanes per wave at which the trace kernel fetches new rays (default 24),
  *   "front_streams"    chunks of a frame in flight at once on internal streams (1..4, default 2; 0 = by frame size: 3 from

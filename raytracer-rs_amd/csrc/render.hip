@@ -80,7 +80,7 @@ static FrontWorkspace g_front_ws;
 static std::atomic<bool> g_render_busy{false};
 static hipEvent_t g_frame_done = nullptr;
 static bool g_frame_done_valid = false;
-static size_t g_front_max_paths = 32u << 20;  // paths per band (628 B of workspace each); env RTM_FRONT_MAX_PATHS
+static size_t g_front_max_paths = 0;  // sample paths in flight at once over the chunks of a frame (~0.5 KB of work space each); 0 = by frame size; env RTM_FRONT_MAX_PATHS
 static uint32_t g_s_threshold = 24, g_t_min_lanes = 32;  // wave scheduler knobs (rt_wave.h); env RTM_S_THRESHOLD / RTM_T_MIN_LANES
 
 // ------------------------------------------------------------------------------------------------
@@ -396,7 +396,7 @@ int rtm_init(int device) {
 int rtm_set_tuning(const char* key, long long value) {
     if (!key) return rtm_internal_fail(RTM_ERR_INVALID, "key is null");
     const std::string k(key);
-    if (k == "front_max_paths" && value >= 64 && value <= (1ll << 31)) { g_front_max_paths = (size_t)value; return RTM_OK; }
+    if (k == "front_max_paths" && (value == 0 || (value >= 64 && value <= (1ll << 31)))) { g_front_max_paths = (size_t)value; return RTM_OK; }  // 0 = by frame size
     if (k == "front_cull" && (value == 0 || value == 1)) { g_front_cull = (uint32_t)value; return RTM_OK; }
     if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
     if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
@@ -713,7 +713,7 @@ struct FrontFixedWs {  // rtm_render_device_noalloc: a work space that is alread
 struct FrontLayout {  // byte offsets of the work space of one chunk
     size_t o_D0, o_D1, o_U0, o_U1, o_fin, o_res, o_itD, o_itU, o_ctr, bytes;
 };
-FrontLayout front_layout(size_t np_max, uint32_t nq) {
+FrontLayout front_layout(size_t np_max, uint32_t nq, uint32_t pf_n, uint32_t pu_n) {
     FrontLayout L{};
     const uint32_t blocks_max = (uint32_t)((np_max + 63) / 64);
     const uint32_t cap_l_max = ((blocks_max + nq - 1) / nq) * 64u;
@@ -721,8 +721,8 @@ FrontLayout front_layout(size_t np_max, uint32_t nq) {
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t items_max = (size_t)nq * cap_l_max * 3u;
     const size_t slots_max = (size_t)nq * cap_l_max;  // path slots (>= np_max: every wave's share is rounded up to whole blocks)
-    L.o_D0 = take(slots_max * rtf::PF_COUNT * 8); L.o_D1 = take(slots_max * rtf::PF_COUNT * 8);
-    L.o_U0 = take(slots_max * rtf::PU_COUNT * 4); L.o_U1 = take(slots_max * rtf::PU_COUNT * 4);
+    L.o_D0 = take(slots_max * pf_n * 8); L.o_D1 = take(slots_max * pf_n * 8);
+    L.o_U0 = take(slots_max * pu_n * 4); L.o_U1 = take(slots_max * pu_n * 4);
     L.o_fin = take(slots_max * 3 * 8); L.o_res = take(slots_max * 3 * sizeof(rtf::FrontResult));
     L.o_itD = take(items_max * rtf::IT_DCOUNT * 8); L.o_itU = take(items_max * rtf::IU_COUNT * 4);
     L.o_ctr = take((size_t)nq * rtf::CT_STRIDE * 4);
@@ -785,6 +785,9 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
             ok(hipEventRecord(prof->ev[kind].back().second, on), "hipEventRecord");
         }
     };
+    // what travels with a path (rt_front.h PF_*, PU_*): the fields behind PF_EFF / PU_HOME exist only for scenes with more than two lights
+    const uint32_t pf_n = sd->view.n_lights > 2u ? (uint32_t)rtf::PF_COUNT : (uint32_t)rtf::PF_NRM;
+    const uint32_t pu_n = sd->view.n_lights > 2u ? (uint32_t)rtf::PU_COUNT : (uint32_t)rtf::PU_LI;
     const uint32_t tiles_x = (p->width + 7) / 8;
     const size_t band_paths = (size_t)tiles_x * 64u * p->spp;  // paths of one 8-row band
     if (band_paths > 0x3FFFFFFFu / 3u) return rtm_internal_fail(RTM_ERR_INVALID, "width x spp too large for one band of paths");
@@ -794,8 +797,20 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
     // (0: three chunks in flight win 1-2 % on the whole bunny frame and lose 4 % on suzanne and on small rank shares: not the default)
     const uint32_t want_conc = g_front_streams ? g_front_streams : (band_paths * bands_total >= ((size_t)12 << 20) ? 3u : 2u);
     const uint32_t n_conc = fixed ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({want_conc, (uint32_t)kFrontStreamsMax, bands_total}));
-    uint32_t bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / n_conc / band_paths);
-    bands_per_chunk = std::min(bands_per_chunk, (bands_total + n_conc - 1) / n_conc);
+    uint32_t bands_per_chunk;
+    if (g_front_max_paths) {
+        bands_per_chunk = (uint32_t)std::max<size_t>(1, g_front_max_paths / n_conc / band_paths);
+        bands_per_chunk = std::min(bands_per_chunk, (bands_total + n_conc - 1) / n_conc);
+    } else {
+        // By frame size: one chunk per internal stream where that is at most 64 Mi sample paths (fewer, larger launches win: the
+        // bunny frame takes 31.9 ms as two chunks, 34.6 ms as four, profiles/r03_chunks.log), else chunks of 64 Mi -- config 5's
+        // 9.4e8 paths run as 15 chunks over ~100 GB of the 288 GB -- and never chunks below 4 Mi paths.
+        const size_t total = band_paths * bands_total;
+        const size_t per_chunk = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)4 << 20, (total + n_conc - 1) / n_conc));
+        uint32_t n_chunks_want = (uint32_t)std::max<size_t>(n_conc, (total + per_chunk - 1) / per_chunk);
+        n_chunks_want = (n_chunks_want + n_conc - 1) / n_conc * n_conc;
+        bands_per_chunk = std::max<uint32_t>(1, (bands_total + n_chunks_want - 1) / n_chunks_want);
+    }
     {   // (pixel of the tile, tile column, tile row of the chunk, sample) of a path travel packed in one word (rt_front.h PU_HOME):
         // width x spp is bounded by front_supported(), the rows of a chunk are bounded here
         auto bits = [](uint32_t n) { uint32_t b = 1; while ((1u << b) < n) ++b; return b; };
@@ -807,16 +822,16 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
     // uses a third of them: every sub-queue owns whole 64-path blocks, which is what a small work space is spent on.)
     const uint32_t nq = (uint32_t)g_num_cus * (fixed ? 8u : g_front_shade_waves_per_cu);
     if (fixed) {  // as many bands at a time as the work space holds
-        while (bands_per_chunk > 1 && front_layout(band_paths * bands_per_chunk, nq).bytes > fixed->bytes) --bands_per_chunk;
-        if (front_layout(band_paths * bands_per_chunk, nq).bytes > fixed->bytes)
+        while (bands_per_chunk > 1 && front_layout(band_paths * bands_per_chunk, nq, pf_n, pu_n).bytes > fixed->bytes) --bands_per_chunk;
+        if (front_layout(band_paths * bands_per_chunk, nq, pf_n, pu_n).bytes > fixed->bytes)
             return rtm_internal_fail(RTM_ERR_INVALID, "frame too wide for the static scratch: one 8-row band of width x spp = " +
                                                           std::to_string((unsigned long long)p->width * p->spp) + " sample paths per row needs " +
-                                                          std::to_string(front_layout(band_paths, nq).bytes >> 20) + " MiB of " +
+                                                          std::to_string(front_layout(band_paths, nq, pf_n, pu_n).bytes >> 20) + " MiB of " +
                                                           std::to_string(fixed->bytes >> 20) + " MiB (lower width or spp, or use rtm_render_device)");
     }
     const size_t np_max = band_paths * bands_per_chunk;
     if (np_max + (size_t)64 * 64 * 1024 >= (1ull << 30)) return rtm_internal_fail(RTM_ERR_INVALID, "band of paths too large");
-    const FrontLayout L = front_layout(np_max, nq);
+    const FrontLayout L = front_layout(np_max, nq, pf_n, pu_n);
     const size_t o_D0 = L.o_D0, o_D1 = L.o_D1, o_U0 = L.o_U0, o_U1 = L.o_U1, o_fin = L.o_fin, o_res = L.o_res, o_itD = L.o_itD,
                  o_itU = L.o_itU, o_ctr = L.o_ctr, ws_one = L.bytes;
     char* ws_base = fixed ? fixed->base : nullptr;
@@ -887,6 +902,7 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
             A.row_begin = p->row_begin; A.row_stride = p->row_stride; A.flags = p->flags;
             A.row0 = band0 * 8; A.rows = std::min(nb * 8, n_rows - band0 * 8);
             A.tiles_x = tiles_x; A.n_tiles = tiles_x * nb; A.npix = A.n_tiles * 64u; A.np = A.npix * p->spp;
+            A.pf_n = pf_n; A.pu_n = pu_n;
             A.cull = (stats && !(prof && prof->keep_cull) && !std::getenv("RTM_DIAG_KEEP_CULL")) ? 0u : g_front_cull;
             // Scenes where most non-empty cells are long (config 5's soup): the box screen leaves about two entries per cell and every
             // cell a ray meets is opened, so two test slots per step and an earlier switch from walking to testing (soup -12 %);

@@ -46,7 +46,7 @@ constexpr uint32_t kMaxCellsPerSide = 512;   // cell coordinates travel packed, 
 constexpr uint32_t kRemGuards = (1u << 9) | (1u << 19) | (1u << 29);  // see `rem` in the trace kernel
 
 // Per-path state, array of structures of arrays: paths in blocks of 64, a block's fields back to back, so double
-// field f of path p is D[at64(PF_COUNT, f, p)] (likewise U, the query results and the trace items).  A wave's
+// field f of path p is D[at64(pf_n, f, p)] (likewise U, the query results and the trace items).  A wave's
 // accesses of one iteration are 512-byte runs inside ONE ~10 KB region; with whole-frame SoA arrays (hundreds of MB
 // apart) every field sat on its own page and address translation, not HBM, set the pace of the shade kernel.
 // Only what the next round cannot recompute travels: 13 doubles and 4 words per live path (11 and 3 with A.rehit and
@@ -105,6 +105,7 @@ struct FrontArgs {
     uint32_t tiles_x, n_tiles;  // 8x8 pixel tiles over W x rows; pixel ids are tile-major
     uint32_t npix, np;          // npix = n_tiles * 64 (ragged tiles padded), np = npix * spp paths.  Logical path = 64-path block
                                 // (sample, tile) x lane; block b is stored at slot (b % nq) * cap_l + (b / nq) * 64: wave b % nq owns it
+    uint32_t pf_n, pu_n;        // doubles / words of path state per path (the strides of D and U): 13 / 4 in scenes with at most two lights, else PF_COUNT / PU_COUNT
     uint32_t cull;              // 1: shadow queries that cannot contribute (eff <= 0.001) are not traced
     uint32_t refill;            // trace kernel: fetch new items when at least this many lanes of a wave are idle
     uint32_t claim, steal;      // trace kernel: items claimed at a time; sub-queues of other waves a wave may try when its own are empty
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
 
     // The flag word of a path is read one iteration ahead: which of the previous round's answers exist (and so where
     // they are) is known when the iteration's loads are issued, instead of one memory latency later.
-    uint32_t flb_next = (!ROUND0 && lane < n_in_list) ? Uin[at64(PU_COUNT, PU_FLB, (size_t)sq * A.cap_l + lane)] : 0u;
+    uint32_t flb_next = (!ROUND0 && lane < n_in_list) ? Uin[at64((int)A.pu_n, PU_FLB, (size_t)sq * A.cap_l + lane)] : 0u;
 #ifdef RTM_SHADE_TIMES
     unsigned long long st_t[5] = {0, 0, 0, 0, 0};  // diagnostics build: cycles waiting for the loads / answers, computing, storing; iterations
 #endif
@@ -238,10 +239,10 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         const uint32_t p = sq * A.cap_l + (valid ? idx : 0u);  // slot read this round
         if (ROUND0) valid = (k * A.nq + sq) < blocks_total;
         const uint32_t flb = flb_next;
-        flb_next = (!ROUND0 && idx + 64u < n_in_list) ? Uin[at64(PU_COUNT, PU_FLB, (size_t)p + 64u)] : 0u;
-        auto ldD = [&](int f) -> double { return Din[at64(PF_COUNT, f, p)]; };
+        flb_next = (!ROUND0 && idx + 64u < n_in_list) ? Uin[at64((int)A.pu_n, PU_FLB, (size_t)p + 64u)] : 0u;
+        auto ldD = [&](int f) -> double { return Din[at64((int)A.pf_n, f, p)]; };
         auto ldD3 = [&](int f) -> V3 { return mk(ldD(f), ldD(f + 1), ldD(f + 2)); };
-        auto ldU = [&](int f) -> uint32_t { return Uin[at64(PU_COUNT, f, p)]; };
+        auto ldU = [&](int f) -> uint32_t { return Uin[at64((int)A.pu_n, f, p)]; };
 
         // which sample of which pixel the path is: packed into one word in round 0 (the wave's k-th block is block
         // k * nq + sq = (sample, tile): divisions of wave-uniform numbers) and carried along -- later rounds unpack it
@@ -654,9 +655,9 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         const unsigned long long alive = __ballot(keep);
         const uint32_t p_out = sq * A.cap_l + n_live_local + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull));
         n_live_local += (uint32_t)__popcll(alive);
-        auto stD = [&](int f, double v) { Dout[at64(PF_COUNT, f, p_out)] = v; };
+        auto stD = [&](int f, double v) { Dout[at64((int)A.pf_n, f, p_out)] = v; };
         auto stD3 = [&](int f, V3 v) { stD(f, v.x); stD(f + 1, v.y); stD(f + 2, v.z); };
-        auto stU = [&](int f, uint32_t v) { Uout[at64(PU_COUNT, f, p_out)] = v; };
+        auto stU = [&](int f, uint32_t v) { Uout[at64((int)A.pu_n, f, p_out)] = v; };
 #ifdef RTM_SHADE_TIMES
         st_d = __builtin_amdgcn_s_memtime();
 #endif
@@ -898,13 +899,13 @@ __global__ __launch_bounds__(kBlock, RTM_FRONT_OCC) void front_trace_kernel(RtmD
                     const uint32_t rg = (li_ >= sq_n0 ? 1u : 0u) + (li_ >= sq_n01 ? 1u : 0u);
                     const size_t it = (size_t)sq * A.cap_i + (size_t)rg * A.cap_l + (li_ - (rg == 0u ? 0u : (rg == 1u ? sq_n0 : sq_n01)));
                     const size_t ps = IU[at64(IU_COUNT, IU_P, it)];
-                    if (rg == 0u) d = mk(Pst[at64(PF_COUNT, PF_D0 + 0, ps)], Pst[at64(PF_COUNT, PF_D0 + 1, ps)], Pst[at64(PF_COUNT, PF_D0 + 2, ps)]);
+                    if (rg == 0u) d = mk(Pst[at64((int)A.pf_n, PF_D0 + 0, ps)], Pst[at64((int)A.pf_n, PF_D0 + 1, ps)], Pst[at64((int)A.pf_n, PF_D0 + 2, ps)]);
                     else d = mk(I[at64(IT_DCOUNT, IT_D + 0, it)], I[at64(IT_DCOUNT, IT_D + 1, it)], I[at64(IT_DCOUNT, IT_D + 2, it)]);
                     tmx = I[at64(IT_DCOUNT, IT_TM + 0, it)]; tmy = I[at64(IT_DCOUNT, IT_TM + 1, it)]; tmz = I[at64(IT_DCOUNT, IT_TM + 2, it)];
                     const uint32_t cw = IU[at64(IU_COUNT, IU_CELL, it)];
                     q = (uint32_t)it;
                     const uint32_t iw = IU[at64(IU_COUNT, IU_M, it)];
-                    o = mk(Pst[at64(PF_COUNT, PF_O + 0, ps)], Pst[at64(PF_COUNT, PF_O + 1, ps)], Pst[at64(PF_COUNT, PF_O + 2, ps)]);
+                    o = mk(Pst[at64((int)A.pf_n, PF_O + 0, ps)], Pst[at64((int)A.pf_n, PF_O + 1, ps)], Pst[at64((int)A.pf_n, PF_O + 2, ps)]);
                     model_i = iw & 0xFFFFu;
                     {   // tDelta = (step sign * cell size) / direction (core.rs:119-125; the product with +-1 is exact)
                         const gptr<double> mc = (gptr<double>)models_g[model_i].cell;

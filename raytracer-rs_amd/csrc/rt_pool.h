@@ -188,12 +188,12 @@ __global__ __launch_bounds__(kPoolBlockMax) void pool_trace_kernel(RtmDevScene S
                 const size_t it = (size_t)sq * A.cap_i + (size_t)rg * A.cap_l + (li_ - (rg == 0u ? 0u : (rg == 1u ? sq_n0 : sq_n01)));
                 const size_t ps = IU[at64(IU_COUNT, IU_P, it)];
                 V3 d;
-                if (rg == 0u) d = mk(Pst[at64(PF_COUNT, PF_D0 + 0, ps)], Pst[at64(PF_COUNT, PF_D0 + 1, ps)], Pst[at64(PF_COUNT, PF_D0 + 2, ps)]);
+                if (rg == 0u) d = mk(Pst[at64((int)A.pf_n, PF_D0 + 0, ps)], Pst[at64((int)A.pf_n, PF_D0 + 1, ps)], Pst[at64((int)A.pf_n, PF_D0 + 2, ps)]);
                 else d = mk(I[at64(IT_DCOUNT, IT_D + 0, it)], I[at64(IT_DCOUNT, IT_D + 1, it)], I[at64(IT_DCOUNT, IT_D + 2, it)]);
                 const double tmx = I[at64(IT_DCOUNT, IT_TM + 0, it)], tmy = I[at64(IT_DCOUNT, IT_TM + 1, it)], tmz = I[at64(IT_DCOUNT, IT_TM + 2, it)];
                 const uint32_t cw = IU[at64(IU_COUNT, IU_CELL, it)];
                 const uint32_t iw = IU[at64(IU_COUNT, IU_M, it)];
-                const V3 o = mk(Pst[at64(PF_COUNT, PF_O + 0, ps)], Pst[at64(PF_COUNT, PF_O + 1, ps)], Pst[at64(PF_COUNT, PF_O + 2, ps)]);
+                const V3 o = mk(Pst[at64((int)A.pf_n, PF_O + 0, ps)], Pst[at64((int)A.pf_n, PF_O + 1, ps)], Pst[at64((int)A.pf_n, PF_O + 2, ps)]);
                 const uint32_t model_i = iw & 0xFFFFu;
                 // tDelta = (step sign * cell size) / direction (core.rs:119-125; the product with +-1 is exact)
                 const gptr<double> mc = (gptr<double>)models_g[model_i].cell;

@@ -121,7 +121,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
             g = s.render(spp=3, seed=4, width=203, height=77)
             assert np.array_equal(g["rgb"], ref["rgb"])
     finally:
-        rtm_gpu.set_tuning("front_max_paths", 32 << 20)
+        rtm_gpu.set_tuning("front_max_paths", 0)
         rtm_gpu.set_tuning("front_cull", 1)
         rtm_gpu.set_tuning("front_refill", 24)
         rtm_gpu.set_tuning("front_streams", 2)
