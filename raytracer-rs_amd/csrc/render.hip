@@ -60,7 +60,7 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_front_ev_pool;
 static size_t g_front_ev_used = 0;
 static uint32_t g_front_pool = 0;  // trace kernel: 1 = rays parked in LDS pools (rt_pool.h) when the scene's bitmaps leave room for them, 0 = one ray per lane (rt_front.h); env RTM_FRONT_POOL
 static uint32_t g_pool_refill = 40, g_pool_walk_more = 40, g_pool_test_frac = 32;  // env RTM_POOL_REFILL / RTM_POOL_WALK_MORE / RTM_POOL_TEST_FRAC
-static int g_pool_rays = 96;  // rays per wave of the pool kernel (72 or 96); env RTM_POOL_R
+static int g_pool_rays = 96;  // rays per wave of the pool kernel (72, with more waves per CU, was measured no better and is not built)
 static uint32_t g_pool_plain = 0, g_pool_waves = 0;  // env RTM_POOL_PLAIN=1: stage the plain occupancy only; RTM_POOL_WAVES: cap on waves per workgroup
 static bool g_front_inlane_force = false;  // the knob was set by hand: also for scenes with many analytic primitives
 static uint32_t g_front_inlane = 24;  // shade kernel: paths advance in the lane while no query of theirs needs the trace kernel, if at least this many lanes of the wave do (0 = never); env RTM_FRONT_INLANE
@@ -363,7 +363,6 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_FRONT_COOP")) g_front_coop = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_POOL")) g_front_pool = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_POOL_REFILL")) g_pool_refill = (uint32_t)std::max(1, std::min(128, std::atoi(e)));
-    if (const char* e = std::getenv("RTM_POOL_R")) g_pool_rays = std::atoi(e) == 72 ? 72 : 96;
     if (const char* e = std::getenv("RTM_POOL_PLAIN")) g_pool_plain = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_POOL_WAVES")) g_pool_waves = (uint32_t)std::max(0, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("RTM_POOL_WALK_MORE")) g_pool_walk_more = (uint32_t)std::max(1, std::min(65, std::atoi(e)));
@@ -999,7 +998,7 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
     }
 #define RTM_POOL_CASE(v, S_, L_, M_)                                                                                                        \
     case v:                                                                                                                                 \
-        if (g_pool_rays == 72) RTM_POOL_LAUNCH(v, S_, L_, M_, 72) else RTM_POOL_LAUNCH(v, S_, L_, M_, 96)                                   \
+        RTM_POOL_LAUNCH(v, S_, L_, M_, 96)                                   \
         break;
                             RTM_POOL_CASE(0, false, false, false) RTM_POOL_CASE(1, false, false, true)
                             RTM_POOL_CASE(2, false, true, false) RTM_POOL_CASE(3, false, true, true)
