@@ -15,7 +15,6 @@ pub const RTM_ERR_IO: c_int = -4;
 pub const RTM_ERR_STATE: c_int = -5;
 
 pub const RTM_FLAG_ZERO_JITTER: u32 = 1;
-pub const RTM_FLAG_KERNEL_V1: u32 = 2;
 pub const RTM_FLAG_KERNEL_WAVE: u32 = 4;
 
 /// Camera fields (camera.rs:4-10).

@@ -88,9 +88,11 @@ typedef struct rtm_scene {
 
 #define RTM_FLAG_ZERO_JITTER 1u /* x_offset = y_offset = 0 (known-answer tests); reference always jitters, main.rs:162-163 */
 
-/* Three device formulations of the same arithmetic exist; all give bit-identical images.  Default: the ray-front
- * pipeline (rt_front.h).  The two flags select the older single-kernel forms (kept as cross-checks). */
-#define RTM_FLAG_KERNEL_V1 2u   /* the straight per-lane kernel (rt_device.h) */
+/* Two device formulations of the same arithmetic exist; both give bit-identical images.  Default: the ray-front
+ * pipeline (rt_front.h).  The flag selects the older single-kernel form, kept as the cross-check the parity tests hold against
+ * the oracle and as the fallback for scenes beyond the ray-front path's packed indices (rtm_front_scene_fits).  (Flag value 2
+ * selected a straight per-lane transliteration until round 3; it is retired and now rejected as an unknown flag -- the same
+ * per-lane code still answers rtm_trace_rays.) */
 #define RTM_FLAG_KERNEL_WAVE 4u /* the wave-scheduled single kernel (rt_wave.h) */
 
 typedef struct rtm_params {

@@ -27,7 +27,6 @@ LIB_PATH = os.environ.get("RTM_LIB_PATH") or os.path.join(_HERE, "lib", "librayt
 INCLUDE_PATH = os.path.join(os.path.dirname(_HERE), "include", "rt_mi355x.h")
 NO_ID = 0xFFFFFFFF
 FLAG_ZERO_JITTER = 1
-FLAG_KERNEL_V1 = 2
 FLAG_KERNEL_WAVE = 4
 STAT_NAMES = ("rays_camera", "rays_bounce", "rays_shadow", "sphere_tests", "plane_tests", "bbox_tests",
               "cells_visited", "tri_tests", "model_hits")
@@ -177,8 +176,8 @@ def set_tuning(key: str, value: int):
 
 
 def make_params(width: int, height: int, spp: int = 1, seed: int = 0, max_bounces: int = 10, row_begin: int = 0,
-                row_stride: int = 1, zero_jitter: bool = False, kernel_v1: bool = False, kernel_wave: bool = False) -> RtmParams:
-    flags = (FLAG_ZERO_JITTER if zero_jitter else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_WAVE if kernel_wave else 0)
+                row_stride: int = 1, zero_jitter: bool = False, kernel_wave: bool = False) -> RtmParams:
+    flags = (FLAG_ZERO_JITTER if zero_jitter else 0) | (FLAG_KERNEL_WAVE if kernel_wave else 0)
     return RtmParams(width, height, spp, max_bounces, seed, row_begin, row_stride, flags, 0)
 
 
@@ -285,12 +284,12 @@ class Scene:
 
     def render(self, spp: int = 1, seed: int = 0, width: int = 0, height: int = 0, max_bounces: int = 10,
                row_begin: int = 0, row_stride: int = 1, zero_jitter: bool = False, ids: bool = True,
-               stats: bool = False, kernel_v1: bool = False, kernel_wave: bool = False) -> dict:
+               stats: bool = False, kernel_wave: bool = False) -> dict:
         """rtm_render: host buffers in, host buffers out (the drop-in for main.rs:153-171)."""
         if not _inited:
             init()
         p = make_params(width or self.width, height or self.height, spp, seed, max_bounces, row_begin, row_stride,
-                        zero_jitter, kernel_v1, kernel_wave)
+                        zero_jitter, kernel_wave)
         rows = local_rows(p)
         rgb = np.zeros((rows, p.width, 3))
         obj = np.zeros((rows, p.width), dtype=np.uint32) if ids else None

@@ -87,12 +87,6 @@ static uint32_t g_s_threshold = 24, g_t_min_lanes = 32;  // wave scheduler knobs
 // kernels
 using namespace rtd;
 
-struct RenderArgs {
-    uint32_t W, H, spp, max_bounces;
-    uint64_t seed;
-    uint32_t row_begin, row_stride, n_rows, flags;
-};
-
 RTM_DEV uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -101,57 +95,6 @@ RTM_DEV uint64_t wave_sum_u64(uint64_t v) {
         v += ((uint64_t)hi << 32) | lo;
     }
     return v;
-}
-
-// One pixel per lane; a wave owns an 8x8 pixel tile, a 256-thread workgroup a 16x16 tile, so the
-// 64 camera rays (and the shadow rays of their first hits) of a wave stay coherent.  All samples of
-// a pixel are accumulated by its lane in sample order (main.rs:159-170), which makes the result
-// independent of the launch geometry and bit-reproducible at any spp.
-template <bool STATS>
-__global__ __launch_bounds__(256) void render_kernel(RtmDevScene S, RenderArgs A, double* __restrict__ out_rgb,
-                                                      uint32_t* __restrict__ out_obj, uint32_t* __restrict__ out_tri,
-                                                      unsigned long long* __restrict__ out_cnt) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t ly = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    Counters cnt;
-    if (STATS)
-        for (int i = 0; i < 9; ++i) cnt.v[i] = 0;
-    const bool live = x < A.W && ly < A.n_rows;
-    if (live) {
-        const uint32_t y = A.row_begin + ly * A.row_stride;
-        const uint32_t pixel = x + A.W * y;  // main.rs:160-161,177
-        V3 px = mk(0, 0, 0);
-        uint32_t obj0 = kNoId, tri0 = kNoId;
-        const double n_spp = (double)A.spp;
-        for (uint32_t s = 0; s < A.spp; ++s) {
-            double xo = 0.0, yo = 0.0;
-            if (!(A.flags & RTM_FLAG_ZERO_JITTER)) {  // main.rs:162-163
-                uint32_t r[4];
-                philox(A.seed, pixel, s, 0u, r);
-                xo = u01(r[0], r[1]) * (0.5 - -0.5) + -0.5;
-                yo = u01(r[2], r[3]) * (0.5 - -0.5) + -0.5;
-            }
-            V3 o, d;
-            camera_ray(S, x, y, A.W, A.H, xo, yo, o, d);
-            uint32_t fo, ft;
-            const V3 c = cast<STATS>(S, o, d, A.seed, pixel, s, (int)A.max_bounces, cnt, fo, ft);
-            if (s == 0) { obj0 = fo; tri0 = ft; }
-            px = px + c / n_spp;  // main.rs:169
-        }
-        const size_t li = (size_t)ly * A.W + x;
-        out_rgb[li * 3] = px.x;
-        out_rgb[li * 3 + 1] = px.y;
-        out_rgb[li * 3 + 2] = px.z;
-        if (out_obj) out_obj[li] = obj0;
-        if (out_tri) out_tri[li] = tri0;
-    }
-    if (STATS) {
-        for (int i = 0; i < 9; ++i) {
-            const uint64_t s = wave_sum_u64(cnt.v[i]);
-            if (lane == 0 && s) atomicAdd(out_cnt + i, (unsigned long long)s);
-        }
-    }
 }
 
 // hit() of caller-supplied rays (differential tests)
@@ -281,6 +224,7 @@ int check_params(const rtm_params* p) {
     if (p->max_bounces == 0 || p->max_bounces > 64) return rtm_internal_fail(RTM_ERR_INVALID, "max_bounces must be 1..64");
     if (p->row_stride == 0 || p->row_begin >= p->height) return rtm_internal_fail(RTM_ERR_INVALID, "bad row_begin/row_stride");
     if ((uint64_t)p->width * p->height > 0xFFFFFFFFull) return rtm_internal_fail(RTM_ERR_INVALID, "image too large");
+    if (p->flags & ~(RTM_FLAG_ZERO_JITTER | RTM_FLAG_KERNEL_WAVE)) return rtm_internal_fail(RTM_ERR_INVALID, "unknown flag (2 was RTM_FLAG_KERNEL_V1, the per-lane kernel retired in round 3)");
     return RTM_OK;
 }
 
@@ -1109,9 +1053,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     if (int rc = check_params(p)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     const uint32_t n_rows = rtm_local_rows(p);
-    const dim3 grid((p->width + 15) / 16, (n_rows + 15) / 16), block(256);
-    const bool v1 = (p->flags & RTM_FLAG_KERNEL_V1) != 0;
-    RenderArgs A{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags};
+    const dim3 block(256);
     rtw::RenderArgsW AW{p->width, p->height, p->spp, p->max_bounces, p->seed, p->row_begin, p->row_stride, n_rows, p->flags,
                         g_s_threshold, g_t_test_frac, g_t_min_lanes, (p->width + 7) / 8, ((p->width + 7) / 8) * ((n_rows + 7) / 8), 0u, g_work_counter};
     {   // occupancy bitmaps that fit the LDS budget, models in order (same rule as the kernel's staging loop)
@@ -1127,7 +1069,7 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
     static const uint32_t wgs_env = std::getenv("RTM_WGS_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("RTM_WGS_PER_CU"))) : 0u;
     const uint32_t wgs_per_cu = wgs_env ? wgs_env : (uint32_t)RTM_WAVE_OCC;
     const uint32_t wave_wgs = std::min<uint32_t>((AW.n_tiles + 3) / 4, (uint32_t)g_num_cus * wgs_per_cu);
-    const bool front = !v1 && !(p->flags & RTM_FLAG_KERNEL_WAVE) && g_kernel == 2 && front_supported(sd, p);
+    const bool front = !(p->flags & RTM_FLAG_KERNEL_WAVE) && g_kernel == 2 && front_supported(sd, p);
     FrameGuard guard;
     if (int rc = guard.enter(stream)) return rc;
     int front_rc = RTM_OK;
@@ -1136,15 +1078,10 @@ int rtm_render_device(const rtm_scene_dev* sd, const rtm_params* p, double* d_rg
             front_rc = render_front(sd, p, n_rows, front_occ_words(sd), d_rgb, d_obj, d_tri, stats ? d_cnt : nullptr, stream);
             return front_rc == RTM_OK ? hipSuccess : hipErrorUnknown;
         }
-        if (v1) {
-            if (stats) hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
-            else hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, sd->view, A, d_rgb, d_obj, d_tri, d_cnt);
-        } else {
-            hipError_t me = hipMemsetAsync(g_work_counter, 0, 256, stream);  // claimed tiles start at 0 every frame
-            if (me != hipSuccess) return me;
-            if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-            else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
-        }
+        hipError_t me = hipMemsetAsync(g_work_counter, 0, 256, stream);  // claimed tiles start at 0 every frame
+        if (me != hipSuccess) return me;
+        if (stats) hipLaunchKernelGGL(rtw::render_wave_kernel<true>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
+        else hipLaunchKernelGGL(rtw::render_wave_kernel<false>, dim3(wave_wgs), block, wave_lds, stream, sd->view, AW, d_rgb, d_obj, d_tri, d_cnt);
         return hipGetLastError();
     };
     if (out_stats) {
@@ -1220,7 +1157,7 @@ int rtm_render_device_noalloc(const rtm_scene_dev* sd, const rtm_params* p, doub
     if (int rc = need_init()) return rc;
     if (!sd || !d_rgb) return rtm_internal_fail(RTM_ERR_INVALID, "scene or output is null");
     if (int rc = check_params(p)) return rc;
-    if (p->flags & (RTM_FLAG_KERNEL_V1 | RTM_FLAG_KERNEL_WAVE)) return rtm_internal_fail(RTM_ERR_INVALID, "rtm_render_device_noalloc runs the ray-front pipeline only");
+    if (p->flags & RTM_FLAG_KERNEL_WAVE) return rtm_internal_fail(RTM_ERR_INVALID, "rtm_render_device_noalloc runs the ray-front pipeline only");
     if (!front_supported(sd, p)) return rtm_internal_fail(RTM_ERR_INVALID, "scene or frame beyond the ray-front pipeline's limits (grid > 512 cells per side, > 429 496 729 list entries or >= 2^27 cells over all models, > 65 535 bounces)");
     if (sd->device != g_device || !g_scratch_ptr[g_device]) return rtm_internal_fail(RTM_ERR_STATE, "scene was uploaded to another device, or rtm_init has not bound the scratch array");
     if (g_render_busy.exchange(true)) return rtm_internal_fail(RTM_ERR_STATE, "another thread is inside a render call (the library is not re-entrant)");
@@ -1261,7 +1198,7 @@ int rtm_profile_render_device(const rtm_scene_dev* sd, const rtm_params* p, doub
     hipStream_t stream = (hipStream_t)stream_;
     *out = rtm_profile{};
     const uint32_t n_rows = rtm_local_rows(p);
-    const bool front = !(p->flags & (RTM_FLAG_KERNEL_V1 | RTM_FLAG_KERNEL_WAVE)) && g_kernel == 2 && front_supported(sd, p);
+    const bool front = !(p->flags & RTM_FLAG_KERNEL_WAVE) && g_kernel == 2 && front_supported(sd, p);
     if (!front) {  // one kernel: its time and the reference-equivalent counters
         double ms = 0.0;
         if (int rc = rtm_time_render_device(sd, p, d_rgb, 1, stream_, &ms)) return rc;

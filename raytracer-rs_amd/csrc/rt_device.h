@@ -1,7 +1,8 @@
-// rt_device.h -- device-side intersect / trace / shade for gfx950 (CDNA4), f64 throughout.
+// rt_device.h -- device-side vector math and the per-lane closest-hit query for gfx950 (CDNA4), f64 throughout: the building
+// blocks of rt_front.h / rt_wave.h and, as scene_hit(), the straight per-lane form of hit() that answers rtm_trace_rays.
 //
-// Replaces, op for op, the reference's hot path (citations relative to /root/reference/src/):
-//   cast main.rs:57-132, hit raytracing/core.rs:68-92, Solid::hit core.rs:180-213,
+// Op for op the reference's (citations relative to /root/reference/src/):
+//   hit raytracing/core.rs:68-92, Solid::hit core.rs:180-213,
 //   ray_intersect core.rs:94-178, Triangle::intersect model.rs:43-74, normal_on_point model.rs:18-39,
 //   Box3::intersect math/box3D.rs:64-93, Camera::shoot_to camera.rs:46-52, Vec3 ops math/vec3.rs.
 // Bit-exactness rules: every expression keeps the reference's grouping; FMA contraction is OFF for
@@ -241,75 +242,6 @@ RTM_DEV V3 hit_normal(const RtmDevScene& S, const Hit& h, V3 o, V3 d, V3 point) 
         return ld3(S.planes + (size_t)h.prim * 4);
     }
     return model_normal(S.models[h.prim], h.tri, point);
-}
-
-// ---- cast (main.rs:57-132) --------------------------------------------------------------------------
-template <bool STATS>
-RTM_DEV V3 cast(const RtmDevScene& S, V3 o, V3 d, uint64_t seed, uint32_t pixel, uint32_t sample, int max_bounces,
-                Counters& cnt, uint32_t& first_obj, uint32_t& first_tri) {
-    V3 color = mk(0, 0, 0);
-    double att = 1.0;
-    for (int bounce = 0; bounce < max_bounces; ++bounce) {
-        if (STATS) cnt.v[bounce == 0 ? C_CAM : C_BOUNCE]++;
-        Hit h;
-        const bool got = scene_hit<STATS>(S, o, d, h, cnt);
-        if (bounce == 0) { first_obj = got ? h.obj : kNoId; first_tri = got ? h.tri : kNoId; }
-        if (!got) {
-            color = color + mk(1, 1, 1) * att;  // main.rs:127
-            break;
-        }
-        const V3 P = ray_at(o, d, h.t);  // core.rs:89
-        V3 nrm = hit_normal(S, h, o, d, P);
-        if (dot(d, nrm) > 0.001) nrm = nrm * -1.0;  // main.rs:68-73
-        V3 diffuse = mk(0, 0, 0);
-        for (uint32_t li = 0; li < S.n_lights; ++li) {  // main.rs:78-105
-            const double* L = S.lights + (size_t)li * 8;
-            const V3 lp = ld3(L);
-            const V3 v = normalize(lp - P);
-            const double dl2 = sqdist(P, lp);
-            if (STATS) cnt.v[C_SHADOW]++;
-            Hit oh;
-            if (scene_hit<STATS>(S, P, v, oh, cnt)) {
-                const double do2 = sqdist(ray_at(P, v, oh.t), P);
-                if (do2 <= dl2) continue;
-            }
-            const double eff = dot(v, nrm);
-            if (eff > 0.001) {
-                const double dd = fmax(dl2 / (L[6] * L[6]), 1.0);
-                const double decay = 1.0 / dd;
-                diffuse = diffuse + ld3(L + 3) * decay * eff;
-            }
-        }
-        const double* mat = S.materials + (size_t)h.mat * 4;
-        const bool metal = mat[3] != 0.0;
-        const double diffuse_k = metal ? 0.2 : 0.9;   // main.rs:108-111
-        const double specular_k = metal ? 0.8 : 0.1;  // main.rs:112-115
-        V3 bd;
-        if (metal) {
-            bd = d - nrm * 2.0 * dot(d, nrm);  // vec3.rs:172-175, not renormalised
-        } else {
-            uint32_t ra[4], rb[4];
-            philox(seed, pixel, sample, 1u + 2u * (uint32_t)bounce, ra);
-            philox(seed, pixel, sample, 2u + 2u * (uint32_t)bounce, rb);
-            const V3 rnd = mk(u01(ra[0], ra[1]) * (1.0 - 0.0) + 0.0, u01(ra[2], ra[3]) * (1.0 - 0.0) + 0.0,
-                              u01(rb[0], rb[1]) * (1.0 - 0.0) + 0.0);
-            bd = normalize(nrm + rnd);  // main.rs:53
-        }
-        color = color + ld3(mat) * att * (diffuse * diffuse_k);  // main.rs:118
-        o = P;
-        d = bd;
-        att *= specular_k;
-    }
-    return color;
-}
-
-// main.rs:160-168
-RTM_DEV void camera_ray(const RtmDevScene& S, uint32_t x, uint32_t y, uint32_t W, uint32_t H, double xo, double yo, V3& o, V3& d) {
-    const double u = ((double)x + xo - (double)W * 0.5) / (double)W;
-    const double v = ((double)y + yo - (double)H * 0.5) / (double)H;
-    const V3 dir = ld3(S.cam_fwd) * S.cam_zoom + ld3(S.cam_up) * v + ld3(S.cam_right) * u;  // camera.rs:47
-    o = ld3(S.cam_pos);
-    d = normalize(dir);
 }
 
 }  // namespace rtd

@@ -7,7 +7,7 @@
 // Why this shape (DESIGN.md "Kernel"): the per-ray arithmetic is fixed by bit parity with the reference, so
 // throughput is decided by (a) how many of a wavefront's 64 lanes do useful work per issued f64 instruction
 // and (b) how many wavefronts a SIMD can hold to cover L2 latency and the long f64 divide/sqrt chains.
-// A straight transliteration of cast()/hit() (rt_device.h, kept as the `v1` kernel) runs at ~10 % lane
+// A straight per-lane transliteration of cast()/hit() (round 1's `v1` kernel, retired in round 3) runs at ~10 % lane
 // utilisation on the bunny scene: shadow rays, bounce rays and the 3D-DDA sit at different code addresses
 // and every DDA loop runs for the slowest lane.  Here
 //   * every lane owns one pixel at a time and walks the reference's sequence

@@ -56,15 +56,15 @@ def test_f64_primitives_are_ieee(rtm_gpu):
         assert same.all(), f"{name}: {int((~same).sum())} of {n} differ, e.g. a={a[~same][0]!r} b={b[~same][0]!r}"
 
 
-KERNELS = {"front": {}, "wave": dict(kernel_wave=True), "v1": dict(kernel_v1=True)}
+KERNELS = {"front": {}, "wave": dict(kernel_wave=True)}
 
 
 @pytest.mark.parametrize("kernel", tuple(KERNELS))
 @pytest.mark.parametrize("name", SCENES)
 def test_full_size_1spp_matches_oracle(name, kernel, rtm_gpu, rtm_scene, oracle_scene):
-    """BASELINE configs 1-4 at the reference's own 1200x1200, 1 spp, same seed; all three device formulations (the
-    ray-front pipeline that is the product path, the wave-scheduled single kernel and the straight per-lane kernel)
-    must give the oracle's bits and its exact work counters."""
+    """BASELINE configs 1-4 at the reference's own 1200x1200, 1 spp, same seed; both device formulations (the
+    ray-front pipeline that is the product path and the wave-scheduled single kernel) must give the oracle's bits and
+    its exact work counters."""
     g = rtm_scene(name).render(spp=1, seed=11, stats=True, **KERNELS[kernel])
     c = oracle_scene(name).render(spp=1, seed=11)
     assert g["rgb"].shape == (1200, 1200, 3)

@@ -1,7 +1,7 @@
 // fetch_calib.hip -- what rocprofv3's FETCH_SIZE reports on gfx950 for the access shapes of the trace kernel: per-lane
 // gathers of 8 and 16 bytes at scattered cache lines, against a coalesced streaming read of known size.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/r3/fetch_calib.hip -o tools/r3/fetch_calib
-// Run:   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir> -- tools/r3/fetch_calib
+// Build: hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o tools/fetch_calib
+// Run:   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir> -- tools/fetch_calib
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -2,7 +2,7 @@
 # GPU-box script: the round's evidence.  Usage: gpu_profiles.sh <tag>   (outputs under gpurun_out/<tag>/)
 # Every GPU step has its own time limit; the script stops at the first failure.
 set -o pipefail
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r03}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 step() { echo "== $*" | tee -a $OUT/steps.log; }
 step bench bunny
@@ -31,7 +31,16 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 cd $R
 step bench soup 3840x3840 at 64 spp
 timeout -k 10 600 python -u bench.py --workload soup --spp 64 --steps 1 --warmup 0 > $OUT/bench_soup.json 2> $OUT/bench_soup.err || { tail -5 $OUT/bench_soup.err; exit 1; }
+step bench lines of BASELINE configs 1-3
+timeout -k 10 200 python -u bench.py --workload simple_sphere --spp 1 --steps 20 --warmup 3 > $OUT/bench_simple_sphere.json 2> $OUT/bench_simple_sphere.err || { tail -5 $OUT/bench_simple_sphere.err; exit 1; }
+for w in multisphere suzanne; do
+  timeout -k 10 250 python -u bench.py --workload $w --steps 10 --warmup 2 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || { tail -5 $OUT/bench_$w.err; exit 1; }
+done
 step other scenes and rank shares
-timeout -k 10 300 python -u tools/time_scenes.py > $OUT/scenes.log 2>&1 || exit 1
-timeout -k 10 300 python -u tools/time_split_streams.py > $OUT/shares.log 2>&1 || exit 1
+timeout -k 10 300 python -u tools/timing.py scenes > $OUT/scenes.log 2>&1 || exit 1
+timeout -k 10 300 python -u tools/timing.py shares --streams 1,2,3 > $OUT/shares.log 2>&1 || exit 1
+timeout -k 10 400 python -u tools/timing.py shares --workload soup --spp 16 > $OUT/shares_soup.log 2>&1 || exit 1
+step lane diagnostics and per-launch durations
+RTM_DIAG=1 RTM_DIAG_KEEP_CULL=1 RTM_FRONT_STREAMS=1 timeout -k 10 120 python -u tools/diag.py bunny 20 > $OUT/diag_bunny.log 2>&1 || exit 1
+timeout -k 10 120 python -u tools/prof_launches.py 8 > $OUT/launches_w8.log 2>&1 || exit 1
 step done
