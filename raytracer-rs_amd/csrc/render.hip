@@ -798,7 +798,15 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
         for (uint32_t i = 0; i < n_conc; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i], g_front_fork, 0));
     }
     const uint32_t B_rounds = std::max<uint32_t>(1, (sd->view.n_lights + 1) / 2);
-    const uint32_t rounds = 2 + std::max<uint32_t>(p->max_bounces, 1) * B_rounds;
+    // paths advance in the lane (rt_front.h) when at least `inlane` lanes of their wave can; 65 = never
+    const uint32_t inlane_on = (g_front_inlane && (g_front_inlane_force || sd->view.n_spheres + sd->view.n_planes <= 16u)) ? g_front_inlane : 65u;
+    // A scene without models has nothing to trace: no trace launches; and a small frame of such a scene (config 1: 1200^2 at 1 spp,
+    // 0.63 -> 0.28 ms) is bound by its 22 launches, so every path runs to its end inside round 0's shade kernel (threshold 1: a
+    // lane goes on whatever the others do).  Larger frames keep the rounds: their compaction is worth more (20 spp: 3.7 against 4.0 ms).
+    const bool no_models = sd->view.n_models == 0u;
+    const bool one_launch = no_models && inlane_on <= 64u && !g_front_inlane_force && band_paths * bands_total <= ((size_t)4 << 20);
+    const uint32_t inlane = one_launch ? 1u : inlane_on;
+    const uint32_t rounds = one_launch ? 1u : 2 + std::max<uint32_t>(p->max_bounces, 1) * B_rounds;
     const dim3 block(256);
     const uint32_t shade_wgs = nq / 4u;
     const bool dense = sd->n_long_cells * 2 >= sd->n_nonempty_cells && sd->n_long_cells > 0;  // most non-empty cells are long (config 5's soup)
@@ -855,7 +863,7 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
             A.wide = g_front_wide ? g_front_wide : (dense ? 2u : (uint32_t)RTM_FTRI_WIDE); A.t_min_lanes = g_t_min_lanes;
             // (scenes with many analytic primitives -- multisphere: 125 discriminants per query -- are bound by that arithmetic: they gain
             // nothing from skipping the state's round trip and lose the compaction: measured 42 -> 44-68 ms, profiles/r03_sweep_inlane.log)
-            A.inlane = (g_front_inlane && (g_front_inlane_force || sd->view.n_spheres + sd->view.n_planes <= 16u)) ? g_front_inlane : 65u; A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop; A.att_replay = (p->max_bounces <= 16u && sd->view.n_materials <= 0xFFFFu) ? g_front_rehit : 0u; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
+            A.inlane = inlane; A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop; A.att_replay = (p->max_bounces <= 16u && sd->view.n_materials <= 0xFFFFu) ? g_front_rehit : 0u; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
             A.occ_words = occ_words;
             A.occ_plain = occ_plain_only ? 1u : 0u;
             // which bitmap word the walk probes (rt_front.h probe()): the arrival direction's, the plain occupancy when
@@ -922,7 +930,7 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
 #endif
                 if (prof && prof->d_items && !prof->keep_cull)
                     hipLaunchKernelGGL(front_sum_items_kernel, dim3(32), dim3(256), 0, stream, A.ctr, nq, prof->d_items);
-                if (r + 1 < rounds) {  // the last round only finalises
+                if (r + 1 < rounds && !no_models) {  // the last round only finalises; scenes without models have no trace items
                     mark(1, false, stream);
                     const size_t lds = (size_t)occ_words * 4;
                     const int variant = (stats ? 4 : 0) | (all_lds ? 2 : 0) | (sd->n_long_cells ? 1 : 0);
