@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         // Shadow queries (j > 0) bring dl2 = |light - o|^2 and `lit`: a sphere or plane that occludes the light settles the
         // query here (its flag FB_C stays clear and no ray goes to the models, unless exact work counters are wanted).
         // The item's path slot (IU_P) is written once the lane knows its next slot, below.
-        size_t it_of0 = 0, it_of1 = 0, it_of2 = 0;
+        uint32_t it_of0 = 0, it_of1 = 0, it_of2 = 0;  // (item indices fit 32 bits: the trace kernel keeps them in a word, too)
         bool item0 = false, item1 = false, item2 = false;
         auto issue = [&](const uint32_t j, const bool go, const V3 dir, const double dl2, const bool lit) __attribute__((always_inline)) {
             bool item = false;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                     I[at64(IT_DCOUNT, IT_TM + 0, it)] = tmx; I[at64(IT_DCOUNT, IT_TM + 1, it)] = tmy; I[at64(IT_DCOUNT, IT_TM + 2, it)] = tmz;
                     A.itU[at64(IU_COUNT, IU_CELL, it)] = (uint32_t)(ix + 1) | ((uint32_t)(iy + 1) << 10) | ((uint32_t)(iz + 1) << 20);
                     A.itU[at64(IU_COUNT, IU_M, it)] = mword;
-                    if (j == 0u) { it_of0 = it; item0 = true; } else if (j == 1u) { it_of1 = it; item1 = true; } else { it_of2 = it; item2 = true; }
+                    if (j == 0u) { it_of0 = (uint32_t)it; item0 = true; } else if (j == 1u) { it_of1 = (uint32_t)it; item1 = true; } else { it_of2 = (uint32_t)it; item2 = true; }
                 }
             }
         };
