@@ -363,6 +363,42 @@ def test_differential_fuzz_random_scenes(rtm_gpu, orc):
         assert np.array_equal(a.render(spp=2, seed=trial, kernel_wave=True)["rgb"], cr["rgb"])
 
 
+def test_grazing_rays_on_long_cells(rtm_gpu, orc):
+    """the box screen of long cells (more than 32 entries: each entry's 8-byte box is tested before its record is
+    read) must not drop a hit the reference accepts when the ray nearly lies in a triangle's plane (small |det|, u and v
+    amplified by 1/det).  Flat patches of many small coplanar triangles -- hundreds per grid cell -- seen edge-on from a
+    camera a hair above / below / exactly in their planes, axis-aligned and tilted, with and without jitter: oracle bits."""
+    rng = np.random.default_rng(5)
+
+    def patch(n, y, tilt):
+        c = np.stack([rng.uniform(-0.6, 0.6, n), np.full(n, y), rng.uniform(4.8, 6.0, n)], axis=1)[:, None, :]
+        e = rng.uniform(-0.03, 0.03, (n, 3, 3))
+        e[:, :, 1] = 0.0                                  # coplanar: every triangle lies in the plane y = const ...
+        pos = c + e
+        pos[:, :, 1] += tilt * pos[:, :, 0]               # ... or in a plane tilted about z
+        pos = pos.astype(np.float32)
+        g = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0])
+        g /= np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
+        return pos.reshape(n, 9), np.repeat(g, 3, axis=0).reshape(n, 9).astype(np.float32)
+
+    for cam_y, tilt in ((0.3, 0.0), (0.3000001, 0.0), (0.2999, 0.0), (0.31, 0.0), (0.3, 1e-4), (0.25, 0.03)):
+        txt = f"size 96 64\ncamera from (0, {cam_y}, 0) to (0, 0.3, 5.5)\nplane (0, 1.0, 0) 2 white\nlight (0, -3, 5) white\nlight (1, 0.3, 0) red"
+        a, b = rtm_gpu.Scene(text=txt), orc.OracleScene(text=txt)
+        for y in (0.3, 0.45):
+            pos, nrm = patch(60000, y, tilt)
+            a.add_triangles(pos, nrm)
+            b.add_triangles(pos, nrm)
+        lens = np.concatenate([np.diff(np.concatenate([[0], m["offsets"]])) for m in a.flat()["models"]])
+        assert (lens > 32).sum() > 500, "the patches must make long cells (the box screen runs only there)"
+        for zero_jitter in (True, False):
+            g = a.render(spp=2, seed=3, stats=True, zero_jitter=zero_jitter)
+            c = b.render(spp=2, seed=3, zero_jitter=zero_jitter)
+            assert_frames_match(g, c, f"grazing cam_y={cam_y} tilt={tilt} zero_jitter={zero_jitter}")
+            assert g["counters"] == c["counters"]
+            assert np.array_equal(a.render(spp=2, seed=3, zero_jitter=zero_jitter)["rgb"], c["rgb"])  # culling and the screen on
+        assert (g["obj_id"] >= 1).any()
+
+
 def test_teapot_and_soup_scene(rtm_gpu, orc):
     """BASELINE config 5 in miniature: a seeded triangle soup plus teapot.obj (no `vn`: geometric normals are
     synthesised on both sides -- NOT reference behaviour, the reference loader refuses this file)."""
