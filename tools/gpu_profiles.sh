@@ -43,4 +43,7 @@ timeout -k 10 400 python -u tools/timing.py shares --workload soup --spp 16 > $O
 step lane diagnostics and per-launch durations
 RTM_DIAG=1 RTM_DIAG_KEEP_CULL=1 RTM_FRONT_STREAMS=1 timeout -k 10 120 python -u tools/diag.py bunny 20 > $OUT/diag_bunny.log 2>&1 || exit 1
 timeout -k 10 120 python -u tools/prof_launches.py 8 > $OUT/launches_w8.log 2>&1 || exit 1
+step paths alive and rays traced per round, without and with the in-lane advance
+RTM_FRONT_INLANE=0 timeout -k 10 120 python -u tools/diag_rounds.py 1 > $OUT/rounds_inlane0.log 2>&1 || exit 1
+timeout -k 10 120 python -u tools/diag_rounds.py 1 > $OUT/rounds_inlane24.log 2>&1 || exit 1
 step done
