@@ -911,10 +911,12 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
                     const bool tabs = sd->view.n_lights <= (uint32_t)rtf::kShadeLights && sd->view.n_materials <= (uint32_t)rtf::kShadeMats &&
                                       sd->view.n_models <= (uint32_t)rtf::kShadeModels && sd->view.n_spheres <= (uint32_t)rtf::kShadeSpheres &&
                                       sd->view.n_planes <= (uint32_t)rtf::kShadePlanes;
-                    const size_t slds = tabs ? rtf::kShadeLdsBytes : 0;
-                    switch ((stats ? 4 : 0) | (r == 0 ? 2 : 0) | (tabs ? 1 : 0)) {
+                    const bool many = sd->view.n_spheres > 4u;
+                    const size_t slds = (tabs ? rtf::kShadeLdsBytes : 0) + (many ? rtf::kShadePackBytes : 0);
+                    switch ((many ? 8 : 0) | (stats ? 4 : 0) | (r == 0 ? 2 : 0) | (tabs ? 1 : 0)) {
 #define RTM_SHADE_CASE(v, S_, R_, T_) \
-    case v: hipLaunchKernelGGL((rtf::front_shade_kernel<S_, R_, T_>), dim3(shade_wgs0), block, slds, stream, sd->view, A, r, d_obj, d_tri, shade_cnt); break;
+    case v: hipLaunchKernelGGL((rtf::front_shade_kernel<S_, R_, T_, false>), dim3(shade_wgs0), block, slds, stream, sd->view, A, r, d_obj, d_tri, shade_cnt); break; \
+    case v + 8: hipLaunchKernelGGL((rtf::front_shade_kernel<S_, R_, T_, true>), dim3(shade_wgs0), block, slds, stream, sd->view, A, r, d_obj, d_tri, shade_cnt); break;
                         RTM_SHADE_CASE(0, false, false, false) RTM_SHADE_CASE(1, false, false, true)
                         RTM_SHADE_CASE(2, false, true, false) RTM_SHADE_CASE(3, false, true, true)
                         RTM_SHADE_CASE(4, true, false, false) RTM_SHADE_CASE(5, true, false, true)

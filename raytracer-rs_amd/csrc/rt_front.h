@@ -30,6 +30,9 @@ using namespace rtd;
 #ifndef RTM_SHADE_OCC
 #define RTM_SHADE_OCC 4  // waves per SIMD the shade kernel's register allocation must leave room for (128 VGPRs: shade and trace waves of concurrent chunks share a SIMD)
 #endif
+#ifndef RTM_MANY_OCC
+#define RTM_MANY_OCC RTM_SHADE_OCC  // ... and for its instantiation for scenes with many spheres
+#endif
 #ifndef RTM_FWALK_UNROLL
 #define RTM_FWALK_UNROLL 4
 #endif
@@ -41,6 +44,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kMaxListEntries = 0xFFFFFFFFu / 10u;  // list positions over all models: a position times 10 (doubles per record) is formed in 32 bits
 constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256, kShadeSpheres = 256, kShadePlanes = 64;  // table sizes the shade kernel keeps in LDS
 constexpr size_t kShadeLdsBytes = (size_t)(kShadeLights * 8 + kShadeMats * 4) * 8 + (size_t)(kShadeModels + kShadeSpheres + kShadePlanes) * 2 * 4;
+constexpr size_t kShadePackBytes = (size_t)(kBlock / 64) * 192 * 4;  // (MANY) one table of 192 (lane, slot) words per wave, behind the tables
 constexpr int kModelTab = 256;               // models whose grid word the trace kernel keeps in LDS
 constexpr uint32_t kMaxCellsPerSide = 512;   // cell coordinates travel packed, 10 bits each, biased by one; the walk's countdown has 9-bit fields
 constexpr uint32_t kRemGuards = (1u << 9) | (1u << 19) | (1u << 29);  // see `rem` in the trace kernel
@@ -162,8 +166,10 @@ RTM_DEV void flush_counters(const Counters& cnt, unsigned long long* out_cnt) {
 // TABS: the light, material and per-model (object, material) tables are staged in LDS (scenes within kShade* entries):
 // the paths of a wave are at different lights and materials, so these are per-lane lookups -- of tables that every wave
 // reads all the time.
-template <bool STATS, bool ROUND0, bool TABS>
-__global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
+// MANY: the scene has more than four spheres, so its queries are bound by the sphere loop (multisphere: 125 discriminants per
+// query): the queries of a wave's three slots are packed into passes of 64 over the spheres (see the end of the pass loop).
+template <bool STATS, bool ROUND0, bool TABS, bool MANY = false>
+__global__ __launch_bounds__(kBlock, MANY ? RTM_MANY_OCC : RTM_SHADE_OCC) void front_shade_kernel(RtmDevScene S, FrontArgs A, uint32_t round, uint32_t* __restrict__ out_obj,
                                                               uint32_t* __restrict__ out_tri, unsigned long long* __restrict__ out_cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     // [kShadeLights * 8] lights, [kShadeMats * 4] materials, then u32 pairs: [kShadeModels] (object, material) of the models and
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 }
                 // ---- 1. the path query: analytic hit, then the model hit the trace kernel found (core.rs:75-83)
                 if (b_take) {
-                    if (A.rehit && !fresh0) {  // the analytic part of the query again, from the ray the state holds
+                    if (!MANY && A.rehit && !fresh0) {  // the analytic part of the query again, from the ray the state holds (A.rehit: at most four primitives)
                         double rb = __builtin_inf();
                         bool rf = false;
                         uint32_t ro = kNoId, rm = 0u, rk = 0u;
@@ -554,7 +560,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
         // The item's path slot (IU_P) is written once the lane knows its next slot, below.
         uint32_t it_of0 = 0, it_of1 = 0, it_of2 = 0;  // (item indices fit 32 bits: the trace kernel keeps them in a word, too)
         bool item0 = false, item1 = false, item2 = false;
-        auto issue = [&](const uint32_t j, const bool go, const V3 dir, const double dl2, const bool lit) __attribute__((always_inline)) {
+        struct AHit { double best; uint32_t found, obj, kp; };  // closest sphere / plane of a query
+        auto issue = [&](const uint32_t j, const bool go, const V3 dir, const double dl2, const bool lit, const AHit* pre) __attribute__((always_inline)) {
             bool item = false;
             int ix = 0, iy = 0, iz = 0;
             double tmx = 0, tmy = 0, tmz = 0;
@@ -563,7 +570,8 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 double best = __builtin_inf();
                 bool found = false;
                 uint32_t b_obj = kNoId, b_mat = 0, b_kp = 0;
-                analytic(o, dir, true, best, found, b_obj, b_mat, b_kp);
+                if (pre) { best = pre->best; found = pre->found != 0u; b_obj = pre->obj; b_kp = pre->kp; }  // (MANY: answered in the packed pass)
+                else analytic(o, dir, true, best, found, b_obj, b_mat, b_kp);
                 bool models = true;
                 if (j == 0u) {
                     ba0 = best;
@@ -621,27 +629,75 @@ __global__ __launch_bounds__(kBlock, RTM_SHADE_OCC) void front_shade_kernel(RtmD
                 }
             }
         };
-        issue(0u, active && go0, dir0, 0.0, false);
         {
             // shadow rays to lights li, li+1 (main.rs:80-85) and what each would add to the diffuse sum (main.rs:96-102)
-            auto shadow = [&](const uint32_t j, const bool go) __attribute__((always_inline)) {
-                V3 dir = mk(0, 0, 1);
-                bool trace = false, lit = false;
-                double dl2 = 0.0;
+            V3 sdir[2] = {mk(0, 0, 1), mk(0, 0, 1)};
+            bool strace[2] = {false, false}, slit[2] = {false, false};
+            double sdl2[2] = {0.0, 0.0};
+            auto shadow_ray = [&](const uint32_t j, const bool go) __attribute__((always_inline)) {
                 if (go) {
                     const V3 lp = light3(li + j, 0);
-                    dir = normalize(lp - o);
-                    dl2 = sqdist(o, lp);
-                    const double eff = dot(dir, nn);
+                    sdir[j] = normalize(lp - o);
+                    sdl2[j] = sqdist(o, lp);
+                    const double eff = dot(sdir[j], nn);
                     if (j == 0u) eff0 = eff; else eff1 = eff;
-                    lit = eff > 0.001;  // main.rs:96: otherwise the query's answer is never used
-                    trace = lit || !A.cull;
-                    if (STATS && !trace) n_culled++;
+                    slit[j] = eff > 0.001;  // main.rs:96: otherwise the query's answer is never used
+                    strace[j] = slit[j] || !A.cull;
+                    if (STATS && !strace[j]) n_culled++;
                 }
-                issue(1u + j, go && trace, dir, dl2, lit);  // (the host turns culling off when exact work counters are wanted)
             };
-            shadow(0u, active && go1);
-            shadow(1u, active && go2);
+            shadow_ray(0u, active && go1);
+            shadow_ray(1u, active && go2);
+            const bool g0 = active && go0, g1 = active && go1 && strace[0], g2 = active && go2 && strace[1];  // (the host turns culling off when exact work counters are wanted)
+            if (MANY) {
+                // The queries of the wave as ONE list, 64 per pass over the spheres: those of slot 0 in lane order, then slot 1,
+                // then slot 2.  (Slot by slot, each pass runs with the lanes that have a query in THAT slot: shadow queries that
+                // face away from their light are culled, paths end, and the passes are half empty.)  The lane that holds query q
+                // of a pass pulls the ray from the lane that made it (register shuffles), runs the analytic primitives on it, and
+                // the makers pull the answers back: the same query with the same operands, evaluated in another lane.
+                const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1), m2 = __ballot(g2), below = (1ull << lane) - 1ull;
+                const uint32_t n0 = (uint32_t)__popcll(m0), n01 = n0 + (uint32_t)__popcll(m1), n012 = n01 + (uint32_t)__popcll(m2);
+                uint32_t* const tab = (uint32_t*)((char*)sh_tab + (TABS ? kShadeLdsBytes : 0)) + (threadIdx.x >> 6) * 192u;  // [192] per wave
+                const uint32_t q0 = (uint32_t)__popcll(m0 & below), q1 = n0 + (uint32_t)__popcll(m1 & below), q2 = n01 + (uint32_t)__popcll(m2 & below);
+                if (g0) tab[q0] = lane;
+                if (g1) tab[q1] = lane | 64u;
+                if (g2) tab[q2] = lane | 128u;
+                __builtin_amdgcn_wave_barrier();
+                AHit h0{__builtin_inf(), 0u, kNoId, 0u}, h1 = h0, h2 = h0;
+                for (uint32_t base = 0; base < n012; base += 64u) {  // (wave-uniform)
+                    const bool have = base + lane < n012;
+                    const uint32_t e = have ? tab[base + lane] : 0u;
+                    const int src = (int)(e & 63u);
+                    const uint32_t slot = e >> 6;
+                    const V3 po = mk(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+                    const V3 p0 = mk(__shfl(dir0.x, src, 64), __shfl(dir0.y, src, 64), __shfl(dir0.z, src, 64));
+                    const V3 p1 = mk(__shfl(sdir[0].x, src, 64), __shfl(sdir[0].y, src, 64), __shfl(sdir[0].z, src, 64));
+                    const V3 p2 = mk(__shfl(sdir[1].x, src, 64), __shfl(sdir[1].y, src, 64), __shfl(sdir[1].z, src, 64));
+                    const V3 pd = sel3(slot == 0u, p0, sel3(slot == 1u, p1, p2));
+                    double best = __builtin_inf();
+                    bool found = false;
+                    uint32_t b_obj = kNoId, b_mat = 0, b_kp = 0;
+                    if (have) analytic(po, pd, true, best, found, b_obj, b_mat, b_kp);
+                    (void)b_mat;
+                    auto fetch = [&](const bool g, const uint32_t q, AHit& h) __attribute__((always_inline)) {
+                        const bool here = g && q >= base && q < base + 64u;  // this lane's query of the slot was answered in this pass
+                        const int from = here ? (int)(q - base) : 0;
+                        const double fb = __shfl(best, from, 64);
+                        const uint32_t ff = (uint32_t)__shfl((int)(found ? 1u : 0u), from, 64);
+                        const uint32_t fo = (uint32_t)__shfl((int)b_obj, from, 64), fk = (uint32_t)__shfl((int)b_kp, from, 64);
+                        if (here) { h.best = fb; h.found = ff; h.obj = fo; h.kp = fk; }
+                    };
+                    fetch(g0, q0, h0); fetch(g1, q1, h1); fetch(g2, q2, h2);
+                }
+                __builtin_amdgcn_wave_barrier();
+                issue(0u, g0, dir0, 0.0, false, &h0);
+                issue(1u, g1, sdir[0], sdl2[0], slit[0], &h1);
+                issue(2u, g2, sdir[1], sdl2[1], slit[1], &h2);
+            } else {
+                issue(0u, g0, dir0, 0.0, false, nullptr);
+                issue(1u, g1, sdir[0], sdl2[0], slit[0], nullptr);
+                issue(2u, g2, sdir[1], sdl2[1], slit[1], nullptr);
+            }
         }
         fl = (fl & ~(3u << FB_NSH_SHIFT)) | (n_sh << FB_NSH_SHIFT);
         // ---- who waits for the trace kernel, who goes round again in the lane
