@@ -149,6 +149,9 @@ const char* rtm_version(void);
  *   "front_inlane"     a path whose bounce and shadow queries all missed the models' boxes advances to its next vertex inside
  *                      the shade kernel's lane when at least this many lanes of the wave do (1..64, default 24; 0 = never: every
  *                      vertex waits a round; -1 = default).  Unless set by hand it is off in scenes with more than 16 spheres and planes,
+ *   "front_inlane_lights"  1 (default): in scenes where "front_inlane" is off by itself (many analytic primitives) and with more than
+ *                      two lights, the further light batches of a vertex are still taken in the lane (every path of the wave is in
+ *                      that state at once, so nothing is lost to divergence),
  *   "front_pool"       1: the trace kernel parks a pool of 96 rays per wave in LDS and runs every walk / test step on up to 64
  *                      rays that are ready for it (rt_pool.h); 0 (default): one ray per lane, in registers.  Measured slower
  *                      (DESIGN.md 4.2), kept as a cross-check; "pool_refill", "pool_walk_more", "pool_test_frac" tune it.

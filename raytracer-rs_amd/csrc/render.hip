@@ -62,6 +62,7 @@ static uint32_t g_front_pool = 0;  // trace kernel: 1 = rays parked in LDS pools
 static uint32_t g_pool_refill = 40, g_pool_walk_more = 40, g_pool_test_frac = 32;  // env RTM_POOL_REFILL / RTM_POOL_WALK_MORE / RTM_POOL_TEST_FRAC
 static int g_pool_rays = 96;  // rays per wave of the pool kernel (72, with more waves per CU, was measured no better and is not built)
 static uint32_t g_pool_plain = 0, g_pool_waves = 0;  // env RTM_POOL_PLAIN=1: stage the plain occupancy only; RTM_POOL_WAVES: cap on waves per workgroup
+static uint32_t g_front_inlane_lights = 1;  // env RTM_FRONT_INLANE_LIGHTS
 static bool g_front_inlane_force = false;  // the knob was set by hand: also for scenes with many analytic primitives
 static uint32_t g_front_inlane = 24;  // shade kernel: paths advance in the lane while no query of theirs needs the trace kernel, if at least this many lanes of the wave do (0 = never); env RTM_FRONT_INLANE
 static uint32_t g_front_rehit = 1;  // shade kernel: scenes with at most four spheres + planes recompute a path query's analytic hit instead of carrying it; env RTM_FRONT_REHIT
@@ -312,6 +313,7 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_POOL_WAVES")) g_pool_waves = (uint32_t)std::max(0, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("RTM_POOL_WALK_MORE")) g_pool_walk_more = (uint32_t)std::max(1, std::min(65, std::atoi(e)));
     if (const char* e = std::getenv("RTM_POOL_TEST_FRAC")) g_pool_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RTM_FRONT_INLANE_LIGHTS")) g_front_inlane_lights = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_INLANE")) { g_front_inlane = (uint32_t)std::max(0, std::min(64, std::atoi(e))); g_front_inlane_force = true; }
     if (const char* e = std::getenv("RTM_FRONT_REHIT")) g_front_rehit = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_STEAL")) g_front_steal = (uint32_t)std::max(0, std::atoi(e));
@@ -347,6 +349,7 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
     if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
     if (k == "front_rehit" && (value == 0 || value == 1)) { g_front_rehit = (uint32_t)value; return RTM_OK; }
+    if (k == "front_inlane_lights" && (value == 0 || value == 1)) { g_front_inlane_lights = (uint32_t)value; return RTM_OK; }
     if (k == "front_inlane" && value == -1) { g_front_inlane = 24; g_front_inlane_force = false; return RTM_OK; }  // back to the default
     if (k == "front_inlane" && value >= 0 && value <= 64) { g_front_inlane = (uint32_t)value; g_front_inlane_force = true; return RTM_OK; }
     if (k == "front_pool" && (value == 0 || value == 1)) { g_front_pool = (uint32_t)value; return RTM_OK; }
@@ -868,7 +871,10 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
             A.wide = g_front_wide ? g_front_wide : (dense ? 2u : (uint32_t)RTM_FTRI_WIDE); A.t_min_lanes = g_t_min_lanes;
             // (scenes with many analytic primitives -- multisphere: 125 discriminants per query -- are bound by that arithmetic: they gain
             // nothing from skipping the state's round trip and lose the compaction: measured 42 -> 44-68 ms, profiles/r03_sweep_inlane.log)
-            A.inlane = inlane; A.claim = g_front_claim; A.steal = g_front_steal; A.coop = g_front_coop; A.att_replay = (p->max_bounces <= 16u && sd->view.n_materials <= 0xFFFFu) ? g_front_rehit : 0u; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
+            // (the light batches in the lane only where the general in-lane advance is off: multisphere 36.9 -> 35.7 ms; simple_sphere at 20 spp loses 7 % with it)
+            A.inlane = inlane; A.inlane_lights = inlane_on > 64u ? g_front_inlane_lights : 0u;
+            A.claim = std::max<uint32_t>(16u, g_front_claim);  // (a claim of nothing would spin the trace kernel for ever)
+            A.steal = g_front_steal; A.coop = g_front_coop; A.att_replay = (p->max_bounces <= 16u && sd->view.n_materials <= 0xFFFFu) ? g_front_rehit : 0u; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
             A.occ_words = occ_words;
             A.occ_plain = occ_plain_only ? 1u : 0u;
             // which bitmap word the walk probes (rt_front.h probe()): the arrival direction's, the plain occupancy when

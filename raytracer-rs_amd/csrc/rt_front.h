@@ -117,6 +117,7 @@ struct FrontArgs {
     uint32_t t_test_frac, t_min_lanes;
     uint32_t att_replay;        // shade kernel: 1 = the attenuation is multiplied up again from the vertices' metal flags (16 bits beside the material) instead of travelling as a double
     uint32_t rehit;             // shade kernel: 1 = the analytic hit of a path query is computed again when its answer is taken (few primitives)
+    uint32_t inlane_lights;     // shade kernel: 1 = the further light batches of a vertex (more than two lights) are taken in the lane
     uint32_t inlane;            // shade kernel: paths whose queries were all settled without the trace kernel advance in the lane when at least this many lanes of the wave do (65 = never)
     uint32_t wide;              // trace kernel: list entries a lane tests per step (at most RTM_FTRI_WIDE)
     uint32_t pool_refill;       // pool trace kernel (rt_pool.h): idle slots of a wave's pool that trigger a refill
@@ -705,7 +706,10 @@ __global__ __launch_bounds__(kBlock, MANY ? RTM_MANY_OCC : RTM_SHADE_OCC) void f
         // (... provided enough lanes of the wave do: a pass with a few lanes costs what a full one costs, and the paths that go
         // through memory instead come back compacted)
         const bool could = active && cont && !pending;
-        const bool again = could && (uint32_t)__popcll(__ballot(could)) >= A.inlane;
+        // (a vertex that still has lights to go -- scenes with more than two -- always goes on in the lane when it can: every path of
+        // the wave that shaded a vertex this pass is in that state, so the next pass is as full as this one)
+        const bool more_lights = (fl & FB_HASV) != 0u && li + n_sh < nL;
+        const bool again = could && ((more_lights && A.inlane_lights != 0u) || (uint32_t)__popcll(__ballot(could)) >= A.inlane);
         const bool keep = active && cont && !again;
         // ---- the slot the path moves to (dense, in the other buffer)
         const unsigned long long alive = __ballot(keep);

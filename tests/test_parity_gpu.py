@@ -113,7 +113,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         for key, value in (("front_max_paths", 64), ("front_max_paths", 26 * 64 * 3 * 4), ("front_cull", 0), ("front_refill", 1),
                            ("front_refill", 64), ("front_streams", 1), ("front_streams", 4), ("front_streams", 0), ("front_claim", 16), ("front_steal", 512),
                            ("front_steal", 0), ("front_coop", 0), ("front_rehit", 0),
-                           ("front_inlane", 0), ("front_inlane", 1), ("front_inlane", 64)):
+                           ("front_inlane", 0), ("front_inlane", 1), ("front_inlane", 64), ("front_inlane_lights", 0)):
             rtm_gpu.set_tuning(key, value)
             g = s.render(spp=3, seed=4, width=203, height=77, stats=True)
             assert_frames_match(g, ref, f"suzanne {key}={value}")
@@ -130,6 +130,7 @@ def test_front_bands_cull_and_refill_do_not_change_bits(rtm_gpu, rtm_scene, orac
         rtm_gpu.set_tuning("front_coop", 1)
         rtm_gpu.set_tuning("front_rehit", 1)
         rtm_gpu.set_tuning("front_inlane", -1)
+        rtm_gpu.set_tuning("front_inlane_lights", 1)
     with pytest.raises(rtm_gpu.RtmError):
         rtm_gpu.set_tuning("no_such_knob", 1)
 
