@@ -152,6 +152,9 @@ const char* rtm_version(void);
  *   "front_inlane_lights"  1 (default): in scenes where "front_inlane" is off by itself (many analytic primitives) and with more than
  *                      two lights, the further light batches of a vertex are still taken in the lane (every path of the wave is in
  *                      that state at once, so nothing is lost to divergence),
+ *   "front_sph_screen" 1 (default): in scenes with more than four spheres a screen in packed f32 (two spheres per instruction) runs in
+ *                      front of the f64 sphere test of core.rs:183-195, which then sees only the few spheres a ray can meet; the
+ *                      screen's margin is a proven bound on what f32 loses, results are bit-identical,
  *   "front_pool"       1: the trace kernel parks a pool of 96 rays per wave in LDS and runs every walk / test step on up to 64
  *                      rays that are ready for it (rt_pool.h); 0 (default): one ray per lane, in registers.  Measured slower
  *                      (DESIGN.md 4.2), kept as a cross-check; "pool_refill", "pool_walk_more", "pool_test_frac" tune it.

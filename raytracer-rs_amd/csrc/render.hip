@@ -65,6 +65,7 @@ static uint32_t g_pool_plain = 0, g_pool_waves = 0;  // env RTM_POOL_PLAIN=1: st
 static uint32_t g_front_inlane_lights = 1;  // env RTM_FRONT_INLANE_LIGHTS
 static bool g_front_inlane_force = false;  // the knob was set by hand: also for scenes with many analytic primitives
 static uint32_t g_front_inlane = 24;  // shade kernel: paths advance in the lane while no query of theirs needs the trace kernel, if at least this many lanes of the wave do (0 = never); env RTM_FRONT_INLANE
+static uint32_t g_front_sph_screen = 1;  // shade kernel, scenes with more than four spheres: packed-f32 screen in front of the f64 sphere tests; env RTM_FRONT_SPH_SCREEN
 static uint32_t g_front_rehit = 1;  // shade kernel: scenes with at most four spheres + planes recompute a path query's analytic hit instead of carrying it; env RTM_FRONT_REHIT
 static uint32_t g_front_coop = 1;  // trace kernel: idle lanes test the entries of the last one or two testing rays of a wave
 static uint32_t g_front_claim = 128, g_front_steal = 8;  // trace kernel: items per claim; other waves' sub-queues tried
@@ -315,6 +316,7 @@ int rtm_init(int device) {
     if (const char* e = std::getenv("RTM_POOL_TEST_FRAC")) g_pool_test_frac = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RTM_FRONT_INLANE_LIGHTS")) g_front_inlane_lights = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_INLANE")) { g_front_inlane = (uint32_t)std::max(0, std::min(64, std::atoi(e))); g_front_inlane_force = true; }
+    if (const char* e = std::getenv("RTM_FRONT_SPH_SCREEN")) g_front_sph_screen = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_REHIT")) g_front_rehit = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("RTM_FRONT_STEAL")) g_front_steal = (uint32_t)std::max(0, std::atoi(e));
     g_front_shade_waves_env = std::getenv("RTM_FRONT_SHADE_WAVES") != nullptr;
@@ -348,6 +350,7 @@ int rtm_set_tuning(const char* key, long long value) {
     if (k == "front_refill" && value >= 1 && value <= 64) { g_front_refill = (uint32_t)value; return RTM_OK; }
     if (k == "front_claim" && value >= 16 && value <= (1 << 20)) { g_front_claim = (uint32_t)value; return RTM_OK; }
     if (k == "front_coop" && (value == 0 || value == 1)) { g_front_coop = (uint32_t)value; return RTM_OK; }
+    if (k == "front_sph_screen" && (value == 0 || value == 1)) { g_front_sph_screen = (uint32_t)value; return RTM_OK; }
     if (k == "front_rehit" && (value == 0 || value == 1)) { g_front_rehit = (uint32_t)value; return RTM_OK; }
     if (k == "front_inlane_lights" && (value == 0 || value == 1)) { g_front_inlane_lights = (uint32_t)value; return RTM_OK; }
     if (k == "front_inlane" && value == -1) { g_front_inlane = 24; g_front_inlane_force = false; return RTM_OK; }  // back to the default
@@ -411,7 +414,25 @@ int rtm_scene_upload(const rtm_scene* s, rtm_scene_dev** out) {
         mat[i * 4] = s->mat_r[i]; mat[i * 4 + 1] = s->mat_g[i]; mat[i * 4 + 2] = s->mat_b[i];
         mat[i * 4 + 3] = s->mat_type[i] ? 1.0 : 0.0;
     }
+    // the spheres in f32 for the shade kernel's screen (rt_front.h analytic(), MANY)
+    std::vector<float> sph_scr((((size_t)s->n_spheres + 31) / 32) * 32 * 4, 0.0f);
+    {
+        double lc = 0.0, r2max = 0.0;
+        bool ok = true;
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {
+            const double c3[3] = {s->sph_cx[i], s->sph_cy[i], s->sph_cz[i]}, r2 = s->sph_r[i] * s->sph_r[i];
+            float* const rec = &sph_scr[(size_t)(i / 2) * 8 + (i & 1)];
+            for (int c = 0; c < 3; ++c) { rec[c * 2] = (float)c3[c]; lc = std::max(lc, std::fabs(c3[c])); ok = ok && std::fabs(c3[c]) < 1e8; }
+            rec[6] = (float)r2;
+            r2max = std::max(r2max, r2);
+            ok = ok && r2 < 1e16;  // (NaN fails both)
+        }
+        V.sph_lc = std::nextafter((float)lc, INFINITY); V.sph_r2max = std::nextafter((float)r2max, INFINITY);
+        V.sph_screen_ok = ok ? 1u : 0u;
+        if (!ok) { V.sph_lc = 0.0f; V.sph_r2max = 0.0f; std::fill(sph_scr.begin(), sph_scr.end(), 0.0f); }
+    }
     int rc;
+    if ((rc = upload(sd, sph_scr, &V.sph_screen))) return fail(rc);
     if ((rc = upload(sd, sph, &V.spheres)) || (rc = upload(sd, sph_ids, &V.sph_ids)) || (rc = upload(sd, pl, &V.planes)) ||
         (rc = upload(sd, pl_ids, &V.pl_ids)) || (rc = upload(sd, li, &V.lights)) || (rc = upload(sd, mat, &V.materials)))
         return fail(rc);
@@ -874,6 +895,7 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
             // (the light batches in the lane only where the general in-lane advance is off: multisphere 36.9 -> 35.7 ms; simple_sphere at 20 spp loses 7 % with it)
             A.inlane = inlane; A.inlane_lights = inlane_on > 64u ? g_front_inlane_lights : 0u;
             A.claim = std::max<uint32_t>(16u, g_front_claim);  // (a claim of nothing would spin the trace kernel for ever)
+            A.sph_screen = g_front_sph_screen;
             A.steal = g_front_steal; A.coop = g_front_coop; A.att_replay = (p->max_bounces <= 16u && sd->view.n_materials <= 0xFFFFu) ? g_front_rehit : 0u; A.rehit = (sd->view.n_spheres + sd->view.n_planes <= 4u) ? g_front_rehit : 0u;
             A.occ_words = occ_words;
             A.occ_plain = occ_plain_only ? 1u : 0u;

@@ -31,7 +31,7 @@ using namespace rtd;
 #define RTM_SHADE_OCC 4  // waves per SIMD the shade kernel's register allocation must leave room for (128 VGPRs: shade and trace waves of concurrent chunks share a SIMD)
 #endif
 #ifndef RTM_MANY_OCC
-#define RTM_MANY_OCC RTM_SHADE_OCC  // ... and for its instantiation for scenes with many spheres
+#define RTM_MANY_OCC 3  // ... and for its instantiation for scenes with many spheres (168 VGPRs: with the packed pass and the f32 screen, 128 spill 116 registers -- multisphere 26.1 ms at four waves, 17.8 at three, 19.4 at two)
 #endif
 #ifndef RTM_FWALK_UNROLL
 #define RTM_FWALK_UNROLL 4
@@ -117,6 +117,7 @@ struct FrontArgs {
     uint32_t t_test_frac, t_min_lanes;
     uint32_t att_replay;        // shade kernel: 1 = the attenuation is multiplied up again from the vertices' metal flags (16 bits beside the material) instead of travelling as a double
     uint32_t rehit;             // shade kernel: 1 = the analytic hit of a path query is computed again when its answer is taken (few primitives)
+    uint32_t sph_screen;        // shade kernel (MANY): 1 = the packed-f32 screen in front of the f64 sphere tests
     uint32_t inlane_lights;     // shade kernel: 1 = the further light batches of a vertex (more than two lights) are taken in the lane
     uint32_t inlane;            // shade kernel: paths whose queries were all settled without the trace kernel advance in the lane when at least this many lanes of the wave do (65 = never)
     uint32_t wide;              // trace kernel: list entries a lane tests per step (at most RTM_FTRI_WIDE)
@@ -288,6 +289,80 @@ __global__ __launch_bounds__(kBlock, MANY ? RTM_MANY_OCC : RTM_SHADE_OCC) void f
                 }
             };
             const double a = dot(dir, dir);
+            if (MANY && A.sph_screen) {
+                // Scenes with many spheres: a SCREEN in packed f32 (two spheres per instruction, operands from scalar loads) finds
+                // the few spheres the ray can meet; only those run core.rs:183-195 in f64, each lane on its own survivors.  The
+                // screen evaluates the same two quantities -- the half discriminant (d.oc)^2 - (d.d)(oc.oc - r^2) and d.oc -- and keeps
+                // a sphere unless one of them is on the missing side by more than a bound on everything f32 lost:
+                //   with L = max|o_i| + max|c_i|, D = max|d_i|, u = 2^-24:  |d.oc error| <= 24 u L D  (kept unless d.oc > 2^-17 L D: the
+                //   near root is positive only for d.oc < 0), |half-discriminant error| <= u D^2 (300 L^2 + 24 r^2)  (kept unless it is
+                //   below -2^-14 D^2 (L^2 + r_max^2)); DESIGN.md section 4.2 has the derivation.  Rays and scenes outside the range
+                //   where f32 neither overflows nor underflows (`tame`) keep every sphere.  Survivors are considered in any order:
+                //   `consider` breaks ties by object index itself.
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                if (STATS && count) cnt.v[C_SPHERE] += S.n_spheres;
+                const float ox = (float)org.x, oy = (float)org.y, oz = (float)org.z, dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
+                const float Lo = fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))), Dm = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
+                const float sc = Lo + S.sph_lc, sc2 = sc * sc + S.sph_r2max;
+                const float md = 0x1p-14f * (Dm * Dm) * sc2, mb = 0x1p-17f * sc * Dm, af = (float)a;
+                const bool tame = Lo < 1e8f && Dm < 1e8f && Dm > 1e-8f && sc2 > 1e-12f && sc2 < 1e17f && S.sph_screen_ok != 0u;
+                const cptr<float> scr = as_const(S.sph_screen);
+                for (uint32_t i0 = 0; i0 < S.n_spheres; i0 += 128u) {  // 128 spheres: four words of survivors, then ONE loop over them
+                    uint32_t sv[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (uint32_t w = 0; w < 4u; ++w) {
+                        const uint32_t j0 = i0 + 32u * w;
+                        if (j0 < S.n_spheres) {  // (wave-uniform)
+                            uint32_t culled = 0;
+                            const uint32_t n_in = min(32u, S.n_spheres - j0), pairs = (n_in + 1u) >> 1;
+                            auto pair = [&](const uint32_t u) __attribute__((always_inline)) {
+                                const cptr<float> t = scr + (size_t)(j0 + 2u * u) * 4u;  // (the table is padded to a multiple of 32 spheres, with zeros)
+                                const f2 cx = {t[0], t[1]}, cy = {t[2], t[3]}, cz = {t[4], t[5]}, r2 = {t[6], t[7]};
+                                const f2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+                                const f2 bh = __builtin_elementwise_fma(ocz, (f2)dz, __builtin_elementwise_fma(ocy, (f2)dy, ocx * dx));
+                                const f2 cc = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, __builtin_elementwise_fma(ocx, ocx, -r2)));
+                                const f2 tt = __builtin_elementwise_fma((f2)af, cc, (f2)(-md));
+                                const f2 dd = __builtin_elementwise_fma(bh, bh, -tt);
+                                const f2 v = __builtin_elementwise_min(dd, mb - bh);  // sign bit = out
+                                culled = __builtin_amdgcn_alignbit(culled, __float_as_uint(v.x), 31);
+                                culled = __builtin_amdgcn_alignbit(culled, __float_as_uint(v.y), 31);
+                            };
+                            if (pairs == 16u) {
+#pragma unroll
+                                for (uint32_t u = 0; u < 16u; ++u) pair(u);
+                            } else {
+#pragma unroll 2
+                                for (uint32_t u = 0; u < pairs; ++u) pair(u);
+                            }
+                            culled <<= 32u - 2u * pairs;  // sphere j0 + k is bit 31 - k
+                            sv[w] = (tame ? ~culled : ~0u) & (~0u << (32u - n_in));
+                        }
+                    }
+                    while (__ballot((sv[0] | sv[1] | sv[2] | sv[3]) != 0u)) {
+                        if ((sv[0] | sv[1] | sv[2] | sv[3]) != 0u) {
+                            const uint32_t w = sv[0] ? 0u : sv[1] ? 1u : sv[2] ? 2u : 3u;
+                            const uint32_t cur = sv[0] ? sv[0] : sv[1] ? sv[1] : sv[2] ? sv[2] : sv[3];
+                            const uint32_t k = (uint32_t)__clz((int)cur), rest = cur & ~(0x80000000u >> k);
+                            sv[0] = w == 0u ? rest : sv[0]; sv[1] = w == 1u ? rest : sv[1]; sv[2] = w == 2u ? rest : sv[2]; sv[3] = w == 3u ? rest : sv[3];
+                            const uint32_t i = i0 + 32u * w + k;
+                            const double* const sp = S.spheres + (size_t)i * 4;
+                            const double cx = sp[0], cy = sp[1], cz = sp[2], r = sp[3];
+                            const V3 oc = org - mk(cx, cy, cz);
+                            const double bb = 2.0 * dot(dir, oc);
+                            const double c = dot(oc, oc) - r * r;
+                            const double disc = bb * bb - 4.0 * a * c;
+                            if (!(disc < 0.0)) {
+                                const double t = (-bb - __builtin_sqrt(disc)) / (2.0 * a);
+                                if (t > kEps && (t < best || (found && t == best))) {
+                                    uint32_t mt, obj;
+                                    prim_ids(i, mt, obj);
+                                    if (t < best || obj < b_obj) { best = t; found = true; b_obj = obj; b_mat = mt; b_kp = i; }
+                                }
+                            }
+                        }
+                    }
+                }
+            } else
             // Solid::Sphere (core.rs:183-195), four at a time: the discriminants are evaluated together (their
             // operands are loaded together), then the few spheres the ray meets take the root, in scene order
             for (uint32_t i0 = 0; i0 < S.n_spheres; i0 += 4u) {

@@ -38,6 +38,10 @@ struct RtmDevScene {
     const uint32_t* sph_ids;  // n_spheres x 2: mat, obj
     const double* planes;     // n_planes x 4: nx ny nz d
     const uint32_t* pl_ids;   // n_planes x 2: mat, obj
+    const float* sph_screen;  // the spheres again for the shade kernel's packed-f32 screen (rt_front.h), two per record: cx0 cx1 cy0 cy1 cz0 cz1
+                              // r0^2 r1^2 rounded to f32, padded with zeros to a multiple of 32 spheres
+    float sph_lc, sph_r2max;  // max |centre component| and max r^2 over the spheres (rounded up)
+    uint32_t sph_screen_ok, sph_reserved;  // 0: some sphere is outside the range the screen's error bound holds for
     const RtmDevModel* models;
     const double* lights;     // n_lights x 8: px py pz r g b radius pad
     const double* materials;  // n_materials x 4: r g b type(0.0|1.0)

@@ -400,6 +400,55 @@ def test_grazing_rays_on_long_cells(rtm_gpu, orc):
         assert (g["obj_id"] >= 1).any()
 
 
+def test_sphere_screen_keeps_every_hit(rtm_gpu, orc):
+    """Scenes with more than four spheres run a packed-f32 screen in front of the f64 sphere tests (rt_front.h analytic(), MANY):
+    it may only drop spheres the reference's f64 test rejects.  Random scenes of 5..300 spheres whose radii and distances span
+    five orders of magnitude (one, two and three blocks of 128; tails that are not multiples of 32), scenes scaled down and up
+    by 1e5, rays tangent to a sphere to the last bit (discriminant exactly 0: core.rs:188 accepts it), a sphere and a camera
+    beyond the range the screen's error bound covers (every sphere is kept there): oracle bits, ids and work counters, with the
+    screen on and off."""
+    rng = np.random.default_rng(11)
+
+    def f(x):  # (the reference's number syntax has no exponent: parser.rs)
+        return np.format_float_positional(float(x), precision=17, unique=True, trim="-")
+
+    def scene(n, scale, spread, cam=None):
+        lines = ["size 48 40", cam or "camera from (%s, %s, %s) to (0, 0, %s)" % (f(0.3 * scale), f(-0.2 * scale), f(-1 * scale), f(5 * scale))]
+        for _ in range(n):
+            c = (rng.uniform(-spread, spread, 3) + np.array([0, 0, 6 + spread])) * scale
+            r = scale * 10 ** rng.uniform(-3, 0.3) * (spread if rng.random() < 0.3 else 1.0)
+            lines.append("sphere (%s, %s, %s) %s %s" % (f(c[0]), f(c[1]), f(c[2]), f(r), rng.choice(["white", "metal:red", "cyan"])))
+        lines.append("plane (0, 1, 0) %s white" % f(2 * spread * scale))
+        for _ in range(3):
+            lines.append("light (%s, %s, %s) white" % tuple(f(v) for v in rng.uniform(-4, 4, 3) * spread * scale))
+        return "\n".join(lines)
+
+    cases = [scene(n, sc, sp) for n, sc, sp in ((5, 1, 3), (31, 1, 3), (33, 1, 3), (64, 1, 30), (127, 1e-5, 3), (129, 1e5, 3), (300, 1, 300), (140, 1, 3))]
+    # the centre ray of a zero-jitter frame runs along +z exactly: spheres it touches in one point
+    tangent = ["size 32 32", "camera from (0, 0, 0) to (0, 0, 1)", "sphere (1, 0, 5) 1 white", "sphere (0, -0.5, 9) 0.5 cyan",
+               "sphere (0.25, 0, 14) 0.25 metal:red", "sphere (0, 3, 20) 3 white"]
+    tangent += ["sphere (%.6f, %.6f, %.6f) 0.3 white" % tuple(rng.uniform(-20, 20, 3) + np.array([0, 0, 40])) for _ in range(60)]
+    tangent += ["light (0, -30, 0) white", "light (5, -3, 2) red"]
+    cases.append("\n".join(tangent))
+    cases.append(scene(40, 1, 3) + "\nsphere (1000000000, 0, 5) 1 white")                            # a sphere out of range: no screen at all
+    cases.append(scene(40, 1, 3, cam="camera from (300000000, 0, 0) to (0, 0, 5)"))                  # rays out of range: every sphere kept
+    try:
+        for k, txt in enumerate(cases):
+            a, b = rtm_gpu.Scene(text=txt), orc.OracleScene(text=txt)
+            for zero_jitter in (True, False):
+                c = b.render(spp=2, seed=k, zero_jitter=zero_jitter)
+                for on in (1, 0):
+                    rtm_gpu.set_tuning("front_sph_screen", on)
+                    g = a.render(spp=2, seed=k, stats=True, zero_jitter=zero_jitter)
+                    assert_frames_match(g, c, f"sphere screen case {k} screen={on} zero_jitter={zero_jitter}")
+                    assert g["counters"] == c["counters"]
+                    assert np.array_equal(a.render(spp=2, seed=k, zero_jitter=zero_jitter)["rgb"], c["rgb"])
+            if k < 8:
+                assert (c["obj_id"] != rtm_gpu.NO_ID).mean() > 0.2
+    finally:
+        rtm_gpu.set_tuning("front_sph_screen", 1)
+
+
 def test_teapot_and_soup_scene(rtm_gpu, orc):
     """BASELINE config 5 in miniature: a seeded triangle soup plus teapot.obj (no `vn`: geometric normals are
     synthesised on both sides -- NOT reference behaviour, the reference loader refuses this file)."""

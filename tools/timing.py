@@ -4,6 +4,7 @@
     python tools/timing.py shares [--workload bunny|soup] [--spp N] [--streams 1,2,3,4]
                                                               rank 0's share (rows y = 0 mod G) for G = 1, 2, 4, 8: the
                                                               strong-scaling proxy (no 8-GPU node is ours to launch on)
+    python tools/timing.py spheres                            the f32 sphere screen on / off for lattices of 5..343 spheres
     python tools/timing.py env                                bunny frame and its G = 8 share under the current RTM_* environment
     python tools/timing.py sweep KEY=V[,V...] ...             one child process per setting (the knobs are read at rtm_init)
 
@@ -39,7 +40,7 @@ def frame_ms(rtm, scene, spp, world=1, iters=5):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=("scenes", "shares", "env", "sweep"))
+    ap.add_argument("mode", choices=("scenes", "shares", "env", "sweep", "spheres"))
     ap.add_argument("settings", nargs="*")
     ap.add_argument("--workload", default="bunny")
     ap.add_argument("--spp", type=int, default=0)
@@ -50,7 +51,24 @@ def main():
             key, vals = st.split("=")
             for v in vals.split(","):
                 env = dict(os.environ, **{"RTM_" + key.upper(): v})
-                subprocess.run([sys.executable, "-u", os.path.abspath(__file__), "env"], env=env, check=True, timeout=300)
+                subprocess.run([sys.executable, "-u", os.path.abspath(__file__), "env", "--workload", a.workload, "--spp", str(a.spp)], env=env, check=True, timeout=300)
+        return
+    if a.mode == "spheres":  # the f32 sphere screen on / off against the number of spheres (a lattice like multisphere.scene's)
+        import torch  # noqa: F401
+        from rtm_loader import load_package
+        rtm = load_package()
+        rtm.init(0)
+        for n in (5, 8, 12, 16, 27, 64, 125, 343):
+            side = max(2, round(n ** (1 / 3)))
+            pts = [(x - side / 2 + 0.5, y - side / 2 + 0.5, 6 + z) for x in range(side) for y in range(side) for z in range(side)][:n]
+            txt = "size 1200 1200\ncamera from (-0.5, -0.5, 0)\n" + "\n".join("sphere (%g, %g, %g) .45 white" % p for p in pts)
+            txt += "\nplane (0, 1, 0) 4 white\nlight (0, -8, 0) white\nlight (4, -6, 2) red\nlight (-4, -6, 2) blue"
+            s = rtm.Scene(text=txt)
+            out = []
+            for on in (1, 0):
+                rtm.set_tuning("front_sph_screen", on)
+                out.append(frame_ms(rtm, s, a.spp or 20)[0])
+            print(f"{n:4d} spheres: screen on {out[0]:7.2f} ms   off {out[1]:7.2f} ms", flush=True)
         return
     if a.mode == "scenes":
         for name in ("simple_sphere", "multisphere", "suzanne", "bunny"):
