@@ -313,8 +313,9 @@ def main():
                          "launches_per_frame_isolated": n_launch_iso if iso_n_out else None,
                          "algorithmic_bytes_per_launch": abytes,
                          "limiter": "valu-issue",
-                         "binding_limit": ("FP64 VALU issue of the analytic primitives (sphere discriminants, plane tests: wave-uniform operands, every lane busy) and the "
-                                           "streamed path state; the scene is L2-resident, see valu" if shade_dominant else
+                         "binding_limit": ("vector issue of the analytic primitives (scenes with more than four spheres: a packed-f32 screen over every sphere, then the f64 test "
+                                           "of core.rs:183-195 on the few spheres a ray can meet; plane tests) and the streamed path state; the scene is L2-resident; "
+                                           "valu counts the REFERENCE's f64 operations, which the screen does not all execute" if shade_dominant else
                                            "VALU issue (f64 triangle tests, f32 box screen) at ~35 of 64 lanes and vector-memory latency of per-lane gathers: "
                                            "the scene and the queues of a round are L2/MALL-resident (measured traffic is a fraction of the algorithmic bytes), see valu and DESIGN.md")},
             "valu": {"achieved_tflops": flops / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,

@@ -30,7 +30,7 @@ os.makedirs(os.path.join(DST, f"{pre}_pmc"), exist_ok=True)
 for wl in ("bunny", "soup"):
     for p in ("fetch", "write", "sq1", "sq2"):
         copy(f"pmc_{wl}_{p}/*/*_counter_collection.csv", f"{pre}_pmc/{wl}_{p}_counter_collection.csv")
-for name in ("scenes.log", "shares.log", "shares_soup.log", "diag_bunny.log", "launches_w8.log", "rounds_inlane0.log", "rounds_inlane24.log", "steps.log"):
+for name in ("scenes.log", "shares.log", "shares_soup.log", "shares_multisphere.log", "sphere_screen.log", "diag_bunny.log", "launches_w8.log", "rounds_inlane0.log", "rounds_inlane24.log", "steps.log"):
     copy(name, f"{pre}_{name}")
 
 

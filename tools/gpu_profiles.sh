@@ -40,6 +40,8 @@ step other scenes and rank shares
 timeout -k 10 300 python -u tools/timing.py scenes > $OUT/scenes.log 2>&1 || exit 1
 timeout -k 10 300 python -u tools/timing.py shares --streams 1,2,3 > $OUT/shares.log 2>&1 || exit 1
 timeout -k 10 400 python -u tools/timing.py shares --workload soup --spp 16 > $OUT/shares_soup.log 2>&1 || exit 1
+timeout -k 10 200 python -u tools/timing.py shares --workload multisphere > $OUT/shares_multisphere.log 2>&1 || exit 1
+timeout -k 10 200 python -u tools/timing.py spheres > $OUT/sphere_screen.log 2>&1 || exit 1
 step lane diagnostics and per-launch durations
 RTM_DIAG=1 RTM_DIAG_KEEP_CULL=1 RTM_FRONT_STREAMS=1 timeout -k 10 120 python -u tools/diag.py bunny 20 > $OUT/diag_bunny.log 2>&1 || exit 1
 timeout -k 10 120 python -u tools/prof_launches.py 8 > $OUT/launches_w8.log 2>&1 || exit 1
