@@ -4,7 +4,7 @@ if the f64 test finds no hit with t > eps.  CPU only -- the device side of the s
 tests/test_parity_gpu.py::test_sphere_screen_keeps_every_hit."""
 import numpy as np
 
-EPS = 1e-6  # core.rs:75 (the oracle's kEps)
+EPS = 1e-5  # core.rs:10
 f32 = np.float32
 
 
