@@ -940,7 +940,7 @@ int render_front_queue(const rtm_scene_dev* sd, const rtm_params* p, uint32_t n_
                                       sd->view.n_models <= (uint32_t)rtf::kShadeModels && sd->view.n_spheres <= (uint32_t)rtf::kShadeSpheres &&
                                       sd->view.n_planes <= (uint32_t)rtf::kShadePlanes;
                     const bool many = sd->view.n_spheres > 4u;
-                    const size_t slds = (tabs ? rtf::kShadeLdsBytes : 0) + (many ? rtf::kShadePackBytes : 0);
+                    const size_t slds = (tabs ? rtf::kShadeLdsBytes : 0) + (many ? rtf::kShadePackBytes : 0) + (many && tabs ? rtf::kShadeSphBytes : 0);
                     switch ((many ? 8 : 0) | (stats ? 4 : 0) | (r == 0 ? 2 : 0) | (tabs ? 1 : 0)) {
 #define RTM_SHADE_CASE(v, S_, R_, T_) \
     case v: hipLaunchKernelGGL((rtf::front_shade_kernel<S_, R_, T_, false>), dim3(shade_wgs0), block, slds, stream, sd->view, A, r, d_obj, d_tri, shade_cnt); break; \

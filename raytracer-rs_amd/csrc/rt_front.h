@@ -44,6 +44,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kMaxListEntries = 0xFFFFFFFFu / 10u;  // list positions over all models: a position times 10 (doubles per record) is formed in 32 bits
 constexpr int kShadeLights = 32, kShadeMats = 256, kShadeModels = 256, kShadeSpheres = 256, kShadePlanes = 64;  // table sizes the shade kernel keeps in LDS
 constexpr size_t kShadeLdsBytes = (size_t)(kShadeLights * 8 + kShadeMats * 4) * 8 + (size_t)(kShadeModels + kShadeSpheres + kShadePlanes) * 2 * 4;
+constexpr size_t kShadeSphBytes = (size_t)kShadeSpheres * 4 * 8;  // (MANY with TABS) the f64 spheres, behind the pack tables: what a lane reads for its screen survivors
 constexpr size_t kShadePackBytes = (size_t)(kBlock / 64) * 192 * 4;  // (MANY) one table of 192 (lane, slot) words per wave, behind the tables
 constexpr int kModelTab = 256;               // models whose grid word the trace kernel keeps in LDS
 constexpr uint32_t kMaxCellsPerSide = 512;   // cell coordinates travel packed, 10 bits each, biased by one; the walk's countdown has 9-bit fields
@@ -185,6 +186,10 @@ __global__ __launch_bounds__(kBlock, MANY ? RTM_MANY_OCC : RTM_SHADE_OCC) void f
         for (uint32_t i = threadIdx.x; i < S.n_models; i += kBlock) { sh_mod[i * 2] = S.models[i].obj; sh_mod[i * 2 + 1] = S.models[i].mat; }
         for (uint32_t i = threadIdx.x; i < S.n_spheres * 2u; i += kBlock) sh_ids[i] = S.sph_ids[i];
         for (uint32_t i = threadIdx.x; i < S.n_planes * 2u; i += kBlock) sh_ids[kShadeSpheres * 2 + i] = S.pl_ids[i];
+        if (MANY) {
+            double* const sh_sph_w = (double*)((char*)sh_tab + kShadeLdsBytes + kShadePackBytes);
+            for (uint32_t i = threadIdx.x; i < S.n_spheres * 4u; i += kBlock) sh_sph_w[i] = S.spheres[i];
+        }
         __syncthreads();
     }
     const uint32_t* const sh_mod = (const uint32_t*)(sh_tab + kShadeLights * 8 + kShadeMats * 4);
@@ -345,8 +350,9 @@ __global__ __launch_bounds__(kBlock, MANY ? RTM_MANY_OCC : RTM_SHADE_OCC) void f
                             const uint32_t k = (uint32_t)__clz((int)cur), rest = cur & ~(0x80000000u >> k);
                             sv[0] = w == 0u ? rest : sv[0]; sv[1] = w == 1u ? rest : sv[1]; sv[2] = w == 2u ? rest : sv[2]; sv[3] = w == 3u ? rest : sv[3];
                             const uint32_t i = i0 + 32u * w + k;
-                            const double* const sp = S.spheres + (size_t)i * 4;
-                            const double cx = sp[0], cy = sp[1], cz = sp[2], r = sp[3];
+                            double cx, cy, cz, r;
+                            if (TABS) { const double* const sp = (const double*)((const char*)sh_tab + kShadeLdsBytes + kShadePackBytes) + i * 4u; cx = sp[0]; cy = sp[1]; cz = sp[2]; r = sp[3]; }
+                            else { const double* const sp = S.spheres + (size_t)i * 4; cx = sp[0]; cy = sp[1]; cz = sp[2]; r = sp[3]; }
                             const V3 oc = org - mk(cx, cy, cz);
                             const double bb = 2.0 * dot(dir, oc);
                             const double c = dot(oc, oc) - r * r;
